@@ -1,0 +1,179 @@
+/*
+ * vitmi.h — C ABI of libvitmi.so, the MI355X (gfx950) kernels behind the ViT
+ * forward/backward training path.
+ *
+ * The reference (khuongnd6/ViT_torch) has no FFI: its hot path is the chain of
+ * stock PyTorch ops executed by `self.model(x)` / `loss.backward()` /
+ * `optimizer.step()` in utils_network.py:418-442.  Each entry point below
+ * replaces one group of those ops; the reference line each one stands in for
+ * is cited next to it.  Nothing here takes a torch type: plain device
+ * pointers, sizes, strides (in ELEMENTS) and a hipStream_t passed as void*.
+ *
+ * Conventions
+ *  - every call only ENQUEUES work on `stream`; no allocation, no sync, no
+ *    global mutable state (safe under hipGraph capture, re-entrant);
+ *  - return 0 on success, <0 for a rejected argument (VITMI_E_*), >0 = the
+ *    hipError_t of a failed launch; vitmi_last_error_string() describes the
+ *    last failure on the calling thread;
+ *  - dtype codes: VITMI_F32 / VITMI_BF16.  "T" below = activation dtype,
+ *    "R" = residual-stream dtype; statistics, biases, LayerNorm/LayerScale
+ *    parameters, gradients of parameters and the loss are always fp32.
+ */
+#ifndef VITMI_H
+#define VITMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VITMI_VERSION 100
+
+enum { VITMI_F32 = 0, VITMI_BF16 = 1 };
+
+enum {
+  VITMI_E_BADARG = -1,    /* null pointer / non-positive size                */
+  VITMI_E_ALIGN = -2,     /* pointer or stride not aligned as required       */
+  VITMI_E_DTYPE = -3,     /* dtype combination not built                     */
+  VITMI_E_SHAPE = -4,     /* shape outside what the kernel supports          */
+  VITMI_E_WORKSPACE = -5  /* workspace too small                             */
+};
+
+int vitmi_version(void);
+const char* vitmi_last_error_string(void);
+
+/* ---------------------------------------------------------------- GEMM ---
+ * C[M,N] = epilogue( sum_k A(m,k) * B(n,k) ), fp32 accumulation.
+ *   A(m,k) = a_kmajor ? A[m*lda + k] : A[k*lda + m]
+ *   B(n,k) = b_kmajor ? B[n*ldb + k] : B[k*ldb + n]
+ * so  nn.Linear forward  y = x W^T      : A=x  (kmajor), B=W  (kmajor)
+ *     input gradient     dx = dy W      : A=dy (kmajor), B=W  (k-minor)
+ *     weight gradient    dW = dy^T x    : A=dy (k-minor), B=x (k-minor)
+ * Replaces nn.Linear / nn.Conv2d(k=s=p) forward and their autograd backward:
+ * models/swin.py:19,21,109,111,304,434; models/cait.py:29-33,101-105; the
+ * classifier head models/vision_all.py:310-319.
+ */
+enum {
+  VITMI_EPI_STORE = 0,     /* C = alpha*acc (+bias[n])                        */
+  VITMI_EPI_BIAS_GELU = 1, /* C2 = acc+bias ; C = gelu_erf(C2)  (Mlp.fc1+act,
+                              models/swin.py:25-26)                           */
+  VITMI_EPI_RESIDUAL = 2,  /* C = R + gamma[n]*(acc+bias[n])    (x + g*f(x),
+                              models/cait.py:148-149, models/swin.py:267-268;
+                              gamma==NULL -> 1)                               */
+  VITMI_EPI_DGELU = 3,     /* C = acc * gelu_erf'(AUX)          (backward of
+                              EPI_BIAS_GELU's activation)                     */
+  VITMI_EPI_PATCH_POS = 4  /* t = m % n_tok:  t==0 ? cls[n]+pos[0,n]
+                              : acc+bias[n]+pos[t,n]   (cat(cls,x)+pos_embed,
+                              models/cait.py:231-234 / DINO prepare_tokens)   */
+};
+
+enum { VITMI_GEMM_AUTO = 0, VITMI_GEMM_GENERIC = 1, VITMI_GEMM_FAST = 2 };
+
+typedef struct vitmi_gemm_desc {
+  int64_t M, N, K;
+  const void* A; int64_t lda; int32_t a_kmajor;
+  const void* B; int64_t ldb; int32_t b_kmajor;
+  int32_t in_dtype;            /* dtype of A, B and AUX                       */
+  int32_t epilogue;
+  void* C; int64_t ldc; int32_t c_dtype;
+  void* C2; int64_t ldc2;      /* second output (same dtype as C) or NULL     */
+  const float* bias;           /* [N] or NULL                                 */
+  const void* R; int64_t ldr; int32_t r_dtype;   /* residual input           */
+  const float* gamma;          /* [N] LayerScale or NULL                      */
+  const void* AUX; int64_t ldaux;                /* pre-activation (DGELU)   */
+  const float* pos; int64_t n_tok; const float* cls; /* PATCH_POS            */
+  float alpha;                 /* scale on acc for EPI_STORE (0 -> 1)        */
+  int32_t accumulate;          /* EPI_STORE fp32 only: C += ...              */
+  int32_t impl;                /* VITMI_GEMM_*                               */
+} vitmi_gemm_desc;
+
+int vitmi_gemm(const vitmi_gemm_desc* d, void* stream);
+/* 1 if the aligned-shape MFMA/LDS-DMA kernel would be used for d, 0 if the
+ * generic strided kernel would (tests assert the hot shapes take the fast one) */
+int vitmi_gemm_uses_fast(const vitmi_gemm_desc* d);
+
+/* ------------------------------------------------------------ LayerNorm --
+ * nn.LayerNorm over the last dim: models/swin.py:198,204,305,436,551
+ * (eps 1e-5), models/cait.py:64,68,137,141,203 (eps 1e-6).  One wavefront
+ * per row, fp32 statistics, rows may be strided (x_stride/y_stride in
+ * elements) so the CLS-only final norm reads x[:,0] in place.
+ * Requires D % 4 == 0, D <= 2048.
+ */
+int vitmi_layernorm_fwd(const void* x, int x_dtype, int64_t x_stride,
+                        const float* gamma, const float* beta,
+                        void* y, int y_dtype, int64_t y_stride,
+                        float* mean, float* rstd,
+                        int64_t M, int64_t D, float eps, void* stream);
+
+size_t vitmi_layernorm_bwd_workspace(int64_t M, int64_t D);
+/* g_out = (g_in ? g_in : 0) + dLN/dx ; gb_out (optional) = cast(g_out);
+ * dgamma/dbeta overwritten (fp32 [D]).  g_in may alias g_out. */
+int vitmi_layernorm_bwd(const void* dy, int dy_dtype, int64_t dy_stride,
+                        const void* x, int x_dtype, int64_t x_stride,
+                        const float* mean, const float* rstd, const float* gamma,
+                        const void* g_in, void* g_out, int g_dtype, int64_t g_stride,
+                        void* gb_out, int gb_dtype, int64_t gb_stride,
+                        float* dgamma, float* dbeta,
+                        int64_t M, int64_t D,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------ Attention --
+ * Multi-head self-attention core: softmax(scale * q k^T) v, fused (scores
+ * never reach HBM).  qkv is the output of the qkv Linear viewed as
+ * [B, N, 3, H, hd] (models/swin.py:120, models/cait.py:113); out is
+ * [B, N, H*hd] ready for the proj Linear (models/swin.py:142).  lse[B,H,N] is
+ * the natural-log-sum-exp of the scaled scores, kept for backward.
+ * hd in {32, 64}.
+ */
+int vitmi_attn_fwd(const void* qkv, void* out, float* lse, int dtype,
+                   int64_t B, int64_t N, int64_t H, int64_t hd, float scale,
+                   void* stream);
+size_t vitmi_attn_bwd_workspace(int64_t B, int64_t N, int64_t H);
+int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout,
+                   const float* lse, void* dqkv, int dtype,
+                   int64_t B, int64_t N, int64_t H, int64_t hd, float scale,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------- Elementwise --*/
+/* fp32 -> bf16 shadow copy of the flat parameter buffer */
+int vitmi_cast(const void* src, int src_dtype, void* dst, int dst_dtype,
+               int64_t n, void* stream);
+
+/* im2col for Conv2d(C, D, kernel=p, stride=p) (models/swin.py:434,445):
+ * x[B,C,H,W] fp32 with element strides (sb,sc,sh,sw) — NCHW or channels_last —
+ * -> rows [B*(cls_rows + (H/p)*(W/p)), C*p*p], k = c*p*p + i*p + j.  With
+ * cls_rows=1 row 0 of every image is zero (placeholder for the CLS token). */
+int vitmi_patchify(const float* x, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                   void* out, int out_dtype,
+                   int64_t B, int64_t C, int64_t H, int64_t W, int64_t p,
+                   int cls_rows, void* stream);
+
+/* out[n] = sum_m x[m*ld + n]  (bias gradients, pos_embed/cls gradients) */
+size_t vitmi_colsum_workspace(int64_t M, int64_t N);
+int vitmi_colsum(const void* x, int dtype, int64_t M, int64_t N, int64_t ld,
+                 float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* nn.CrossEntropyLoss() (main.py:244, utils_network.py:430), mean reduction:
+ * loss[0] = mean_b( -log_softmax(logits[b])[label[b]] ), loss[1+b] = the
+ * per-sample terms; dlogits = (softmax - onehot) / B  (gradient for dloss = 1).
+ * correct[0] = count of argmax==label (utils_network.py:85-95), correct[1+b]
+ * the per-sample 0/1.  `loss` must hold 1+B floats and `correct` 1+B int32 —
+ * the per-sample slots double as the scratch of the two-stage, deterministic
+ * reduction, so the call needs no workspace. */
+int vitmi_softmax_xent(const float* logits, const int64_t* labels,
+                       float* loss, float* dlogits, int32_t* correct,
+                       int64_t B, int64_t K, void* stream);
+
+/* optim.SGD(momentum) step (utils_network.py:120,442) over a flat buffer:
+ * buf = momentum*buf + grad_scale*g ; p -= lr*buf ; optional bf16 shadow
+ * refresh of p in the same pass. */
+int vitmi_sgd_momentum(float* p, const float* g, float* buf, void* p_shadow_bf16,
+                       int64_t n, float lr, float momentum, float grad_scale,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITMI_H */

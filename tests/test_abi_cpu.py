@@ -1,0 +1,60 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and
+exports every symbol include/vitmi.h declares (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "vitmi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vitmi_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_something():
+    syms = declared_symbols()
+    assert "vitmi_gemm" in syms and "vitmi_attn_fwd" in syms and len(syms) >= 15
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from vit_torch_amd import _lib
+    raw = ctypes.CDLL(str(_lib.LIB_PATH))
+    for s in declared_symbols():
+        assert hasattr(raw, s), f"libvitmi.so does not export {s}"
+        assert s in _lib.SIGNATURES, f"_lib.SIGNATURES has no binding for {s}"
+    assert set(_lib.SIGNATURES) == set(declared_symbols())
+
+
+def test_version_and_error_string(lib):
+    assert lib.vitmi_version() == 100
+    assert isinstance(lib.vitmi_last_error_string(), bytes)
+
+
+def test_bad_arguments_are_rejected_without_a_gpu(lib):
+    from vit_torch_amd._lib import GemmDesc
+    d = GemmDesc()
+    rc = lib.vitmi_gemm(ctypes.byref(d), None)       # M=N=K=0 -> rejected before any launch
+    assert rc == -1
+    assert b"M,N,K" in lib.vitmi_last_error_string()
+    assert lib.vitmi_layernorm_fwd(None, 0, 0, None, None, None, 0, 0, None, None, 4, 8, 1e-6, None) == -1
+    assert lib.vitmi_layernorm_bwd_workspace(50432, 768) == 512 * 2 * 768 * 4
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from vit_torch_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", tmp_path / "nope.so")
+    with pytest.raises(_lib.VitmiError):
+        _lib.load()
+
+
+def test_cpu_tensor_is_refused():
+    import torch
+    from vit_torch_amd import VisionTransformer, VitmiError
+    m = VisionTransformer(img_size=32, patch_size=16, embed_dim=64, depth=1, num_heads=1)
+    with pytest.raises(VitmiError):
+        m(torch.zeros(1, 3, 32, 32))

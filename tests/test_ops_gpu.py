@@ -1,0 +1,320 @@
+"""GPU parity of every C-ABI op against plain fp32 PyTorch math on the CPU.
+
+fp32 kernels: tolerance 2e-5 relative to max|ref| (fp32 accumulation order).
+bf16 kernels: inputs are rounded to bf16 BEFORE the reference sees them; the
+tolerance 1.5e-2 covers the bf16 rounding of the stored output (2^-8 = 3.9e-3
+of each value) plus bf16 rounding of in-kernel operands (P in attention).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import assert_close, bf16_round
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 2e-5, torch.bfloat16: 1.5e-2}
+
+
+@pytest.fixture(scope="module")
+def ops(lib):
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from vit_torch_amd import ops as _ops
+    return _ops
+
+
+def gen(shape, seed, scale=1.0):
+    g = torch.Generator("cpu").manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def dev(t, dt=torch.float32):
+    return t.to(device="cuda", dtype=dt)
+
+
+def gelu_grad(x):
+    x = x.clone().requires_grad_(True)
+    F.gelu(x).sum().backward()
+    return x.grad
+
+
+# ------------------------------------------------------------------ gemm ---
+SHAPES = [(64, 64, 32), (197, 10, 768), (130, 75, 40), (5, 384, 96), (256, 3, 8), (333, 129, 65)]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("akm,bkm", [(True, True), (True, False), (False, False), (False, True)])
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_gemm_generic_layouts(ops, dt, akm, bkm, M, N, K):
+    from vit_torch_amd._lib import GEMM_GENERIC
+    a = gen((M, K), 1)
+    b = gen((N, K), 2)
+    if dt == torch.bfloat16:
+        a, b = bf16_round(a), bf16_round(b)
+    want = a @ b.t()
+    A = dev(a if akm else a.t().contiguous(), dt)
+    B = dev(b if bkm else b.t().contiguous(), dt)
+    C = torch.empty((M, N), device="cuda", dtype=torch.float32)
+    ops.gemm(A, B, C, a_kmajor=akm, b_kmajor=bkm, impl=GEMM_GENERIC)
+    assert_close("gemm", C, want, 2e-5 if dt == torch.float32 else 1e-5 * math.sqrt(K) + 2e-5)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gemm_epilogues(ops, dt):
+    from vit_torch_amd._lib import (EPI_BIAS_GELU, EPI_DGELU, EPI_PATCH_POS, EPI_RESIDUAL, GEMM_GENERIC)
+    M, N, K = 150, 72, 48
+    rd = (lambda t: bf16_round(t)) if dt == torch.bfloat16 else (lambda t: t)
+    a, b = rd(gen((M, K), 3)), rd(gen((N, K), 4, 0.2))
+    bias = gen((N,), 5)
+    A, B, bias_d = dev(a, dt), dev(b, dt), dev(bias)
+    acc = a @ b.t()
+    tol = TOL[dt]
+    # bias + alpha, bf16/fp32 output
+    C = torch.empty((M, N), device="cuda", dtype=dt)
+    ops.gemm(A, B, C, bias=bias_d, alpha=0.5, impl=GEMM_GENERIC)
+    assert_close("store", C, 0.5 * acc + bias, tol)
+    # accumulate into fp32
+    C32 = dev(gen((M, N), 6))
+    ops.gemm(A, B, C32, accumulate=True, impl=GEMM_GENERIC)
+    assert_close("accumulate", C32, gen((M, N), 6) + acc, tol)
+    # bias + GELU with the pre-activation as second output
+    H = torch.empty((M, N), device="cuda", dtype=dt)
+    P = torch.empty((M, N), device="cuda", dtype=dt)
+    ops.gemm(A, B, H, epilogue=EPI_BIAS_GELU, bias=bias_d, C2=P, impl=GEMM_GENERIC)
+    assert_close("pre", P, acc + bias, tol)
+    assert_close("gelu", H, F.gelu(rd(acc + bias)), tol)
+    # residual with LayerScale, both residual dtypes
+    for rdt in ([torch.float32] if dt == torch.float32 else [torch.float32, torch.bfloat16]):
+        r = gen((M, N), 7)
+        if rdt == torch.bfloat16:
+            r = bf16_round(r)
+        gam = gen((N,), 8)
+        X = torch.empty((M, N), device="cuda", dtype=rdt)
+        ops.gemm(A, B, X, epilogue=EPI_RESIDUAL, bias=bias_d, R=dev(r, rdt), gamma=dev(gam), impl=GEMM_GENERIC)
+        assert_close(f"residual[{rdt}]", X, r + gam * (acc + bias), TOL[rdt])
+        ops.gemm(A, B, X, epilogue=EPI_RESIDUAL, R=dev(r, rdt), impl=GEMM_GENERIC)
+        assert_close(f"residual-plain[{rdt}]", X, r + acc, TOL[rdt])
+    # dgelu
+    aux = rd(gen((M, N), 9))
+    Dg = torch.empty((M, N), device="cuda", dtype=dt)
+    ops.gemm(A, B, Dg, epilogue=EPI_DGELU, aux=dev(aux, dt), impl=GEMM_GENERIC)
+    assert_close("dgelu", Dg, acc * gelu_grad(aux), tol)
+    # patch + pos (+cls): M = 6 images x 25 tokens
+    n_tok = 25
+    pos, cls = gen((n_tok, N), 10), gen((N,), 11)
+    t = torch.arange(M) % n_tok
+    want = acc + bias + pos[t]
+    want[t == 0] = cls + pos[0]
+    for rdt in ([torch.float32] if dt == torch.float32 else [torch.float32, torch.bfloat16]):
+        X = torch.empty((M, N), device="cuda", dtype=rdt)
+        ops.gemm(A, B, X, epilogue=EPI_PATCH_POS, bias=bias_d, pos=dev(pos), n_tok=n_tok, cls=dev(cls), impl=GEMM_GENERIC)
+        assert_close(f"patch_pos[{rdt}]", X, want, TOL[rdt])
+        ops.gemm(A, B, X, epilogue=EPI_PATCH_POS, bias=bias_d, pos=dev(pos), n_tok=n_tok, impl=GEMM_GENERIC)
+        assert_close(f"patch_pos_nocls[{rdt}]", X, acc + bias + pos[t], TOL[rdt])
+
+
+# ------------------------------------------------------------- layernorm ---
+@pytest.mark.parametrize("M,D", [(7, 64), (197, 768), (33, 384), (10, 96), (5, 1536), (4, 2048)])
+@pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
+                                     (torch.bfloat16, torch.bfloat16)])
+def test_layernorm_fwd(ops, M, D, xdt, ydt):
+    x = gen((M, D), 1) * 2 + 0.5
+    if xdt == torch.bfloat16:
+        x = bf16_round(x)
+    g, b = 1 + 0.1 * gen((D,), 2), 0.1 * gen((D,), 3)
+    want = F.layer_norm(x, (D,), g, b, eps=1e-6)
+    y = torch.empty((M, D), device="cuda", dtype=ydt)
+    mean = torch.empty(M, device="cuda")
+    rstd = torch.empty(M, device="cuda")
+    ops.layernorm_fwd(dev(x, xdt), dev(g), dev(b), y, mean, rstd, 1e-6)
+    assert_close("ln.y", y, want, TOL[ydt])
+    assert_close("ln.mean", mean, x.mean(-1), 1e-5)
+    assert_close("ln.rstd", rstd, (x.var(-1, unbiased=False) + 1e-6).rsqrt(), 1e-5)
+
+
+def test_layernorm_fwd_strided_cls_rows(ops):
+    B, N, D = 6, 5, 64
+    x = gen((B, N, D), 4)
+    g, b = 1 + 0.1 * gen((D,), 2), 0.1 * gen((D,), 3)
+    y = torch.empty((B, D), device="cuda")
+    ops.layernorm_fwd(dev(x), dev(g), dev(b), y, None, None, 1e-5, M=B, D=D, x_stride=N * D, y_stride=D)
+    assert_close("ln.cls", y, F.layer_norm(x[:, 0], (D,), g, b, eps=1e-5), 2e-5)
+
+
+@pytest.mark.parametrize("M,D", [(9, 64), (394, 768), (1030, 96), (2100, 384)])
+@pytest.mark.parametrize("T,R", [(torch.float32, torch.float32), (torch.bfloat16, torch.float32),
+                                 (torch.bfloat16, torch.bfloat16)])
+def test_layernorm_bwd(ops, M, D, T, R):
+    rT = (lambda t: bf16_round(t)) if T == torch.bfloat16 else (lambda t: t)
+    rR = (lambda t: bf16_round(t)) if R == torch.bfloat16 else (lambda t: t)
+    x = rR(gen((M, D), 1) * 1.5 + 0.3)
+    dy = rT(gen((M, D), 2))
+    gin = rR(gen((M, D), 3))
+    g = 1 + 0.1 * gen((D,), 4)
+    b = 0.1 * gen((D,), 5)
+    xr = x.clone().requires_grad_(True)
+    gr = g.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    F.layer_norm(xr, (D,), gr, br, eps=1e-6).backward(dy)
+    mean = x.mean(-1)
+    rstd = (x.var(-1, unbiased=False) + 1e-6).rsqrt()
+    G = dev(gin, R)
+    Gb = torch.empty((M, D), device="cuda", dtype=T) if T != R else None
+    dg = torch.empty(D, device="cuda")
+    db = torch.empty(D, device="cuda")
+    ops.layernorm_bwd(dev(dy, T), dev(x, R), dev(mean), dev(rstd), dev(g), G, G, Gb, dg, db)
+    assert_close("ln.g_out", G, gin + xr.grad, TOL[R])
+    if Gb is not None:
+        assert_close("ln.gb_out", Gb, gin + xr.grad, TOL[T])
+    assert_close("ln.dgamma", dg, gr.grad, 1e-4)
+    assert_close("ln.dbeta", db, br.grad, 1e-4)
+
+
+def test_layernorm_bwd_cls_rows_no_gin(ops):
+    B, N, D = 6, 5, 64
+    x = gen((B, N, D), 1)
+    dy = gen((B, D), 2)
+    g = 1 + 0.1 * gen((D,), 4)
+    xr = x[:, 0].clone().requires_grad_(True)
+    F.layer_norm(xr, (D,), g, torch.zeros(D), eps=1e-6).backward(dy)
+    mean = x[:, 0].mean(-1)
+    rstd = (x[:, 0].var(-1, unbiased=False) + 1e-6).rsqrt()
+    G = torch.zeros((B * N, D), device="cuda")
+    dg = torch.empty(D, device="cuda")
+    db = torch.empty(D, device="cuda")
+    ops.layernorm_bwd(dev(dy), dev(x), dev(mean), dev(rstd), dev(g), None, G, None, dg, db,
+                      M=B, D=D, dy_stride=D, x_stride=N * D, g_stride=N * D)
+    want = torch.zeros(B, N, D)
+    want[:, 0] = xr.grad
+    assert_close("ln.cls.g", G.view(B, N, D), want, 2e-5)
+    assert_close("ln.cls.db", db, dy.sum(0), 1e-5)
+
+
+# -------------------------------------------------------------- attention ---
+def attn_ref(qkv, B, N, H, hd, scale):
+    """softmax(scale * q k^T) v on [B,N,3,H,hd] (models/swin.py:120-142 without bias/mask)."""
+    q, k, v = qkv.view(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-2, -1)) * scale
+    lse = torch.logsumexp(s, dim=-1)
+    o = (s.softmax(-1) @ v).transpose(1, 2).reshape(B, N, H * hd)
+    return o, lse
+
+
+ATTN_CASES = [(2, 197, 3, 64), (3, 5, 2, 64), (1, 145, 2, 64), (2, 49, 3, 32), (1, 300, 1, 64),
+              (2, 64, 2, 32), (1, 785, 1, 64), (1, 1, 1, 64)]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,N,H,hd", ATTN_CASES)
+def test_attention_fwd_bwd(ops, dt, B, N, H, hd):
+    scale = hd ** -0.5
+    qkv = gen((B, N, 3 * H * hd), 1)
+    do = gen((B, N, H * hd), 2)
+    if dt == torch.bfloat16:
+        qkv, do = bf16_round(qkv), bf16_round(do)
+    qr = qkv.clone().requires_grad_(True)
+    o_ref, lse_ref = attn_ref(qr, B, N, H, hd, scale)
+    o_ref.backward(do)
+    QKV = dev(qkv, dt)
+    O = torch.empty((B, N, H * hd), device="cuda", dtype=dt)
+    lse = torch.empty(B * H * N, device="cuda")
+    ops.attn_fwd(QKV, O, lse, B, N, H, hd, scale)
+    tol = TOL[dt]
+    assert_close("attn.out", O, o_ref.detach(), tol)
+    assert_close("attn.lse", lse.view(B, H, N), lse_ref.detach(), 1e-5 if dt == torch.float32 else 2e-3)
+    dqkv = torch.full((B, N, 3 * H * hd), float("nan"), device="cuda").to(dt)
+    # feed backward the kernel's own (rounded) output, as the engine does
+    ops.attn_bwd(QKV, O, dev(do, dt), lse, dqkv, B, N, H, hd, scale)
+    g = qr.grad.view(B, N, 3, H, hd)
+    d = dqkv.float().cpu().view(B, N, 3, H, hd)
+    for i, nm in enumerate("qkv"):
+        assert_close(f"attn.d{nm}", d[:, :, i], g[:, :, i], tol if dt == torch.float32 else 2.5e-2)
+
+
+def test_attention_online_softmax_rescale_branch(ops):
+    """Force the running max to jump in the LAST key tile (guide §5.4 rule 26)."""
+    B, N, H, hd = 1, 200, 1, 64
+    qkv = gen((B, N, 3 * H * hd), 3) * 0.5
+    v = qkv.view(B, N, 3, H, hd)
+    v[0, 197, 1, 0] = v[0, 7, 0, 0] * 6.0        # key 197 aligned with query 7 -> huge score
+    qkv = bf16_round(qkv)
+    o_ref, _ = attn_ref(qkv, B, N, H, hd, hd ** -0.5)
+    O = torch.empty((B, N, H * hd), device="cuda", dtype=torch.bfloat16)
+    lse = torch.empty(B * H * N, device="cuda")
+    ops.attn_fwd(dev(qkv, torch.bfloat16), O, lse, B, N, H, hd, hd ** -0.5)
+    assert_close("attn.rescale", O, o_ref, 1.5e-2)
+
+
+# ------------------------------------------------------------ elementwise ---
+@pytest.mark.parametrize("n", [4, 1000, 4099, 1 << 20])
+def test_cast(ops, n):
+    x = gen((n,), 1)
+    y = torch.empty(n, device="cuda", dtype=torch.bfloat16)
+    ops.cast(dev(x), y)
+    assert torch.equal(y.cpu(), x.to(torch.bfloat16))     # round-to-nearest-even, bit exact
+    z = torch.empty(n, device="cuda")
+    ops.cast(y, z)
+    assert torch.equal(z.cpu(), x.to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("B,C,H,p,cls", [(2, 3, 32, 16, 1), (3, 3, 96, 8, 1), (2, 3, 56, 4, 0), (1, 5, 32, 16, 1)])
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_patchify(ops, B, C, H, p, cls, channels_last):
+    x = gen((B, C, H, H), 1)
+    xd = dev(x)
+    if channels_last:
+        xd = xd.contiguous(memory_format=torch.channels_last)
+    want = F.unfold(x, kernel_size=p, stride=p).transpose(1, 2)            # [B, L, C*p*p]
+    if cls:
+        want = torch.cat([torch.zeros(B, 1, want.shape[-1]), want], dim=1)
+    out = torch.empty((want.shape[0] * want.shape[1], want.shape[2]), device="cuda")
+    ops.patchify(xd, out, p, cls)
+    assert torch.equal(out.cpu(), want.reshape(out.shape))
+    outb = torch.empty(out.shape, device="cuda", dtype=torch.bfloat16)
+    ops.patchify(xd, outb, p, cls)
+    assert torch.equal(outb.cpu(), want.reshape(out.shape).to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("M,N", [(1, 8), (50, 10), (777, 768), (4000, 2304), (256, 197 * 64), (33, 7)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_colsum(ops, M, N, dt):
+    x = gen((M, N), 1)
+    if dt == torch.bfloat16:
+        x = bf16_round(x)
+    out = torch.empty(N, device="cuda")
+    ops.colsum(dev(x, dt), out)
+    assert_close("colsum", out, x.double().sum(0).float(), 1e-5)
+
+
+@pytest.mark.parametrize("B,K", [(1, 10), (256, 10), (130, 768), (7, 1000)])
+def test_softmax_xent(ops, B, K):
+    logits = gen((B, K), 1) * 3
+    labels = torch.randint(0, K, (B,), generator=torch.Generator("cpu").manual_seed(2))
+    lr = logits.clone().requires_grad_(True)
+    loss_ref = F.cross_entropy(lr, labels)
+    loss_ref.backward()
+    loss = torch.empty(1 + B, device="cuda")
+    correct = torch.empty(1 + B, device="cuda", dtype=torch.int32)
+    dl = torch.empty((B, K), device="cuda")
+    ops.softmax_xent(dev(logits), labels.cuda(), loss, dl, correct)
+    assert abs(loss[0].item() - loss_ref.item()) <= 2e-6 * max(1.0, abs(loss_ref.item()))
+    assert_close("xent.dlogits", dl, lr.grad, 2e-5)
+    assert correct[0].item() == (logits.argmax(-1) == labels).sum().item()
+
+
+def test_sgd_momentum_two_steps_match_torch(ops):
+    n = 10007
+    p0, g1, g2 = gen((n,), 1), gen((n,), 2), gen((n,), 3)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.SGD([ref], lr=0.01, momentum=0.9)
+    p = dev(p0)
+    buf = torch.zeros(n, device="cuda")
+    shadow = torch.empty(n, device="cuda", dtype=torch.bfloat16)
+    for g in (g1, g2):
+        ref.grad = g.clone()
+        opt.step()
+        ops.sgd_momentum(p, dev(g), buf, shadow, 0.01, 0.9)
+    assert_close("sgd.p", p, ref.data, 1e-6)
+    assert torch.equal(shadow.cpu(), p.cpu().to(torch.bfloat16))

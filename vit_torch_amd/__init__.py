@@ -1,0 +1,8 @@
+"""vit_torch_amd — MI355X-native ViT forward/backward training path (libvitmi)."""
+from ._lib import VitmiError  # noqa: F401
+from .loss import CrossEntropyLoss  # noqa: F401
+from .optim import FusedSGD  # noqa: F401
+from .vision_all import VisionModelZoo  # noqa: F401
+from .vit import VisionTransformer  # noqa: F401
+
+__all__ = ["VisionModelZoo", "VisionTransformer", "CrossEntropyLoss", "FusedSGD", "VitmiError"]

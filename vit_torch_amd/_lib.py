@@ -1,0 +1,91 @@
+"""ctypes binding of libvitmi.so (include/vitmi.h).
+
+The product path has no CPU or PyTorch fallback: if the shared object is
+missing or a call fails, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+LIB_PATH = HERE / "libvitmi.so"
+
+F32, BF16 = 0, 1
+EPI_STORE, EPI_BIAS_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_PATCH_POS = 0, 1, 2, 3, 4
+GEMM_AUTO, GEMM_GENERIC, GEMM_FAST = 0, 1, 2
+
+c_i64, c_i32, c_f32, c_vp, c_sz = C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_size_t
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("M", c_i64), ("N", c_i64), ("K", c_i64),
+        ("A", c_vp), ("lda", c_i64), ("a_kmajor", c_i32),
+        ("B", c_vp), ("ldb", c_i64), ("b_kmajor", c_i32),
+        ("in_dtype", c_i32), ("epilogue", c_i32),
+        ("C", c_vp), ("ldc", c_i64), ("c_dtype", c_i32),
+        ("C2", c_vp), ("ldc2", c_i64),
+        ("bias", c_vp),
+        ("R", c_vp), ("ldr", c_i64), ("r_dtype", c_i32),
+        ("gamma", c_vp),
+        ("AUX", c_vp), ("ldaux", c_i64),
+        ("pos", c_vp), ("n_tok", c_i64), ("cls", c_vp),
+        ("alpha", c_f32), ("accumulate", c_i32), ("impl", c_i32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol declared in include/vitmi.h
+SIGNATURES = {
+    "vitmi_version": (C.c_int, []),
+    "vitmi_last_error_string": (C.c_char_p, []),
+    "vitmi_gemm": (C.c_int, [C.POINTER(GemmDesc), c_vp]),
+    "vitmi_gemm_uses_fast": (C.c_int, [C.POINTER(GemmDesc)]),
+    "vitmi_layernorm_fwd": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, c_vp, c_vp, C.c_int, c_i64,
+                                      c_vp, c_vp, c_i64, c_i64, c_f32, c_vp]),
+    "vitmi_layernorm_bwd_workspace": (c_sz, [c_i64, c_i64]),
+    "vitmi_layernorm_bwd": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, C.c_int, c_i64, c_vp, c_vp, c_vp,
+                                      c_vp, c_vp, C.c_int, c_i64, c_vp, C.c_int, c_i64, c_vp, c_vp,
+                                      c_i64, c_i64, c_vp, c_sz, c_vp]),
+    "vitmi_attn_fwd": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_i64, c_f32, c_vp]),
+    "vitmi_attn_bwd_workspace": (c_sz, [c_i64, c_i64, c_i64]),
+    "vitmi_attn_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_i64,
+                                 c_f32, c_vp, c_sz, c_vp]),
+    "vitmi_cast": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, c_i64, c_vp]),
+    "vitmi_patchify": (C.c_int, [c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, C.c_int, c_i64, c_i64,
+                                 c_i64, c_i64, c_i64, C.c_int, c_vp]),
+    "vitmi_colsum_workspace": (c_sz, [c_i64, c_i64]),
+    "vitmi_colsum": (C.c_int, [c_vp, C.c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_sz, c_vp]),
+    "vitmi_softmax_xent": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
+    "vitmi_sgd_momentum": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_vp]),
+}
+
+_lib = None
+
+
+class VitmiError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libvitmi.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise VitmiError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(python -m vit_torch_amd.build). There is no CPU/PyTorch fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().vitmi_last_error_string()
+        raise VitmiError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")

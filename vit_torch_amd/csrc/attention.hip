@@ -1,0 +1,468 @@
+// Fused multi-head self-attention, bf16 operands / fp32 accumulation on
+// v_mfma_f32_32x32x16_bf16, scores never leave the CU.
+//
+// Layouts: qkv [B, N, 3, H, hd] (output of the qkv Linear), out/dout
+// [B, N, H, hd], lse/delta [B, H, N] fp32.
+//
+// Forward (one wave = 32 query rows, one workgroup = 4 waves = 128 rows of one
+// (b, h); K/V tiles of 64 keys staged in LDS):
+//   S^T[key][q] = K·Q^T        A = K rows (ds_read_b128), B = Q rows (registers)
+//   online softmax over keys   the query is on the LANE, so max/sum/rescale are
+//                              lane-local (+1 cross-half shuffle)
+//   O^T[d][q]  += V^T·P^T      A = V^T via ds_read_b64_tr_b16, B = the S^T
+//                              accumulator itself re-used as operand (guide §3,
+//                              "An accumulator tile as the next MFMA's operand")
+// Backward = two kernels with the same building blocks and no atomics:
+//   dkdv: wave = 32 keys,   S = Q·K^T, dP = dO·V^T (key on the lane),
+//         dV^T += dO^T·P, dK^T += Q^T·dS
+//   dq:   wave = 32 queries, S^T, dP^T (query on the lane), dQ^T += K^T·dS^T
+// 7 MFMA products instead of the minimal 5, but no dQ reduction across waves.
+#include "common.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+__device__ __forceinline__ bf16x4 ds_read_tr16(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, p));
+}
+
+// A-operand fragment of mfma_32x32x16 for X^T where X is an LDS image
+// [image row = k][image col] (bf16, `stride` bytes per row): lane l gets
+// A[row = cbase32 + (l&31)][k slot (h, j)] with k(h, j) = kbase16 + 8*(j>>2) +
+// 4*h + (j&3) — the order in which a 32x32 accumulator presents its rows when
+// it is re-used as the other operand.
+__device__ __forceinline__ bf16x8 load_tr_frag(const char* img, int stride, int kbase16,
+                                               int cbase32, int lane) {
+  const int h5 = lane >> 5, grp = (lane >> 4) & 1, i = lane & 15;
+  const char* p = img + (kbase16 + 4 * h5 + (i >> 2)) * stride + (cbase32 + 16 * grp + 4 * (i & 3)) * 2;
+  const bf16x4 lo = ds_read_tr16(p);
+  const bf16x4 hi = ds_read_tr16(p + 8 * stride);
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+
+// stage ROWS rows x HD bf16 from global (token stride `ts` elements) into LDS
+// rows of SB bytes; rows >= N are zero-filled
+template <int HD, int ROWS, int SB>
+__device__ __forceinline__ void stage_rows(char* lds, const bf16* g, int64_t ts, int row0, int N,
+                                           int tid) {
+  constexpr int CPR = HD / 8;
+#pragma unroll
+  for (int c = tid; c < ROWS * CPR; c += 256) {
+    const int r = c / CPR, cc = c % CPR;
+    const int gr = row0 + r;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
+    if (gr < N) v = *reinterpret_cast<const bf16x8*>(g + (int64_t)gr * ts + cc * 8);
+    *reinterpret_cast<bf16x8*>(lds + r * SB + cc * 16) = v;
+  }
+}
+
+template <int HD> struct AttnCfg {
+  static constexpr int KS = HD * 2 + 16;              // row reads conflict-free
+  static constexpr int VS = HD == 64 ? 192 : 64;      // tr reads conflict-free
+  static constexpr int KSTEPS = HD / 16;
+  static constexpr int DB = HD / 32;
+};
+
+__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int base) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (bf16)v[base + j];
+  return r;
+}
+
+template <int HD>
+__device__ __forceinline__ void store_T_tile(bf16* dst_row, const f32x16 (&acc)[HD / 32], float mul,
+                                             int h5) {
+  // acc[db][reg]: row (d) = db*32 + 8*(reg>>2) + 4*h5 + (reg&3)
+#pragma unroll
+  for (int db = 0; db < HD / 32; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (bf16)(acc[db][4 * g + e] * mul);
+      *reinterpret_cast<bf16x4*>(dst_row + db * 32 + 8 * g + 4 * h5) = o;
+    }
+}
+
+// ------------------------------------------------------------- forward ---
+template <int HD>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv,
+                                                       bf16* __restrict__ out,
+                                                       float* __restrict__ lse, int N, int H,
+                                                       float scale_log2e) {
+  using C = AttnCfg<HD>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Kl = smem;
+  char* Vl = smem + 64 * C::KS;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int lr = lane & 31, h5 = lane >> 5;
+  const int bh = blockIdx.y, b = bh / H, h = bh % H;
+  const int64_t ts = (int64_t)3 * H * HD;
+  const bf16* qb = qkv + (int64_t)b * N * ts + h * HD;
+  const bf16* kb_ = qb + H * HD;
+  const bf16* vb = qb + 2 * H * HD;
+  const int q0 = blockIdx.x * 128 + w * 32;
+  const int qrow = min(q0 + lr, N - 1);
+
+  bf16x8 qf[C::KSTEPS];
+#pragma unroll
+  for (int s = 0; s < C::KSTEPS; ++s)
+    qf[s] = *reinterpret_cast<const bf16x8*>(qb + (int64_t)qrow * ts + 16 * s + 8 * h5);
+
+  f32x16 o[C::DB];
+#pragma unroll
+  for (int db = 0; db < C::DB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+
+  const int nkt = (N + 63) / 64;
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+    stage_rows<HD, 64, C::KS>(Kl, kb_, ts, kt * 64, N, tid);
+    stage_rows<HD, 64, C::VS>(Vl, vb, ts, kt * 64, N, tid);
+    __syncthreads();
+
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < C::KSTEPS; ++ks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Kl + (kb * 32 + lr) * C::KS + (16 * ks + 8 * h5) * 2);
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s[kb], 0, 0, 0);
+      }
+    }
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 64 + kb * 32 + mfma32_row(r, h5);
+        const float v = key < N ? s[kb][r] * scale_log2e : -INFINITY;
+        s[kb][r] = v;
+        tmax = fmaxf(tmax, v);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m, tmax);
+    const float alpha = exp2f(m - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = exp2f(s[kb][r] - m_new);
+        s[kb][r] = p;
+        psum += p;
+      }
+    psum += __shfl_xor(psum, 32);
+    l = l * alpha + psum;
+    m = m_new;
+#pragma unroll
+    for (int db = 0; db < C::DB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = pack8(s[kb], 8 * s2);
+#pragma unroll
+        for (int db = 0; db < C::DB; ++db) {
+          const bf16x8 a = load_tr_frag(Vl, C::VS, kb * 32 + 16 * s2, db * 32, lane);
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf, o[db], 0, 0, 0);
+        }
+      }
+  }
+
+  const int q = q0 + lr;
+  if (q < N) {
+    store_T_tile<HD>(out + ((int64_t)(b * (int64_t)N + q) * H + h) * HD, o, 1.f / l, h5);
+    if (h5 == 0) lse[(int64_t)bh * N + q] = (m + log2f(l)) * LN2;
+  }
+}
+
+// ------------------------------------------------------ backward: delta ---
+// delta[b,h,n] = sum_d dout[b,n,h,d] * out[b,n,h,d]
+template <int HD>
+__global__ void attn_delta_kernel(const bf16* __restrict__ out, const bf16* __restrict__ dout,
+                                  float* __restrict__ delta, int64_t rows, int N, int H) {
+  constexpr int LPR = HD / 8;   // lanes per (b,n,h) row
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row = gid / LPR;
+  const int ch = (int)(gid % LPR);
+  float s = 0.f;
+  if (row < rows) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(out + row * HD + ch * 8);
+    const bf16x8 d = *reinterpret_cast<const bf16x8*>(dout + row * HD + ch * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += (float)a[e] * (float)d[e];
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (row < rows && ch == 0) {
+    const int h = (int)(row % H);
+    const int64_t bn = row / H;
+    const int n = (int)(bn % N);
+    const int64_t b = bn / N;
+    delta[(b * H + h) * N + n] = s;
+  }
+}
+
+// ------------------------------------------------- backward: dK and dV ---
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16* __restrict__ qkv,
+                                                            const bf16* __restrict__ dout,
+                                                            const float* __restrict__ lse,
+                                                            const float* __restrict__ delta,
+                                                            bf16* __restrict__ dqkv, int N, int H,
+                                                            float scale, float scale_log2e) {
+  using C = AttnCfg<HD>;
+  constexpr int QS = C::KS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ql = smem;
+  char* dOl = smem + 32 * QS;
+  float* lse_s = reinterpret_cast<float*>(smem + 64 * QS);
+  float* del_s = lse_s + 32;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int lr = lane & 31, h5 = lane >> 5;
+  const int bh = blockIdx.y, b = bh / H, h = bh % H;
+  const int64_t ts = (int64_t)3 * H * HD;
+  const int64_t os = (int64_t)H * HD;
+  const bf16* qb = qkv + (int64_t)b * N * ts + h * HD;
+  const bf16* kb_ = qb + H * HD;
+  const bf16* vb = qb + 2 * H * HD;
+  const bf16* dob = dout + (int64_t)b * N * os + h * HD;
+  const int key0 = blockIdx.x * 128 + w * 32;
+  const int krow = min(key0 + lr, N - 1);
+
+  bf16x8 kf[C::KSTEPS], vf[C::KSTEPS];
+#pragma unroll
+  for (int s = 0; s < C::KSTEPS; ++s) {
+    kf[s] = *reinterpret_cast<const bf16x8*>(kb_ + (int64_t)krow * ts + 16 * s + 8 * h5);
+    vf[s] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)krow * ts + 16 * s + 8 * h5);
+  }
+  f32x16 dk[C::DB], dv[C::DB];
+#pragma unroll
+  for (int db = 0; db < C::DB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+
+  const int nqt = (N + 31) / 32;
+  for (int qt = 0; qt < nqt; ++qt) {
+    __syncthreads();
+    stage_rows<HD, 32, QS>(Ql, qb, ts, qt * 32, N, tid);
+    stage_rows<HD, 32, QS>(dOl, dob, os, qt * 32, N, tid);
+    if (tid < 32) {
+      const int q = qt * 32 + tid;
+      lse_s[tid] = q < N ? lse[(int64_t)bh * N + q] * LOG2E : INFINITY;
+      del_s[tid] = q < N ? delta[(int64_t)bh * N + q] : 0.f;
+    }
+    __syncthreads();
+
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < C::KSTEPS; ++ks) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ql + lr * QS + (16 * ks + 8 * h5) * 2);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf[ks], s, 0, 0, 0);
+    }
+#pragma unroll
+    for (int ks = 0; ks < C::KSTEPS; ++ks) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(dOl + lr * QS + (16 * ks + 8 * h5) * 2);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, vf[ks], dp, 0, 0, 0);
+    }
+    // rows = query index inside the tile, cols (lane) = key
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qi = mfma32_row(r, h5);
+      const float p = exp2f(s[r] * scale_log2e - lse_s[qi]);
+      s[r] = p;
+      dp[r] = p * (dp[r] - del_s[qi]);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const bf16x8 pf = pack8(s, 8 * s2);
+      const bf16x8 dsf = pack8(dp, 8 * s2);
+#pragma unroll
+      for (int db = 0; db < C::DB; ++db) {
+        const bf16x8 a = load_tr_frag(dOl, QS, 16 * s2, db * 32, lane);
+        dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf, dv[db], 0, 0, 0);
+        const bf16x8 a2 = load_tr_frag(Ql, QS, 16 * s2, db * 32, lane);
+        dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, dsf, dk[db], 0, 0, 0);
+      }
+    }
+  }
+  const int key = key0 + lr;
+  if (key < N) {
+    bf16* row = dqkv + (int64_t)(b * (int64_t)N + key) * ts + h * HD;
+    store_T_tile<HD>(row + H * HD, dk, scale, h5);
+    store_T_tile<HD>(row + 2 * H * HD, dv, 1.f, h5);
+  }
+}
+
+// --------------------------------------------------------- backward: dQ ---
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv,
+                                                          const bf16* __restrict__ dout,
+                                                          const float* __restrict__ lse,
+                                                          const float* __restrict__ delta,
+                                                          bf16* __restrict__ dqkv, int N, int H,
+                                                          float scale, float scale_log2e) {
+  using C = AttnCfg<HD>;
+  constexpr int KS = C::KS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Kl = smem;
+  char* Vl = smem + 64 * KS;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int lr = lane & 31, h5 = lane >> 5;
+  const int bh = blockIdx.y, b = bh / H, h = bh % H;
+  const int64_t ts = (int64_t)3 * H * HD;
+  const int64_t os = (int64_t)H * HD;
+  const bf16* qb = qkv + (int64_t)b * N * ts + h * HD;
+  const bf16* kb_ = qb + H * HD;
+  const bf16* vb = qb + 2 * H * HD;
+  const bf16* dob = dout + (int64_t)b * N * os + h * HD;
+  const int q0 = blockIdx.x * 128 + w * 32;
+  const int qrow = min(q0 + lr, N - 1);
+
+  bf16x8 qf[C::KSTEPS], dof[C::KSTEPS];
+#pragma unroll
+  for (int s = 0; s < C::KSTEPS; ++s) {
+    qf[s] = *reinterpret_cast<const bf16x8*>(qb + (int64_t)qrow * ts + 16 * s + 8 * h5);
+    dof[s] = *reinterpret_cast<const bf16x8*>(dob + (int64_t)qrow * os + 16 * s + 8 * h5);
+  }
+  const float lse_q = lse[(int64_t)bh * N + qrow] * LOG2E;
+  const float del_q = delta[(int64_t)bh * N + qrow];
+  f32x16 dq[C::DB];
+#pragma unroll
+  for (int db = 0; db < C::DB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
+
+  const int nkt = (N + 63) / 64;
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+    stage_rows<HD, 64, KS>(Kl, kb_, ts, kt * 64, N, tid);
+    stage_rows<HD, 64, KS>(Vl, vb, ts, kt * 64, N, tid);
+    __syncthreads();
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16 st, dpt;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < C::KSTEPS; ++ks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Kl + (kb * 32 + lr) * KS + (16 * ks + 8 * h5) * 2);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], st, 0, 0, 0);
+      }
+#pragma unroll
+      for (int ks = 0; ks < C::KSTEPS; ++ks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Vl + (kb * 32 + lr) * KS + (16 * ks + 8 * h5) * 2);
+        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, dof[ks], dpt, 0, 0, 0);
+      }
+      // zero-filled K/V rows (key >= N) give finite p and dS, and multiply a
+      // zero K^T row below, so no masking is needed here
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = exp2f(st[r] * scale_log2e - lse_q);
+        st[r] = p * (dpt[r] - del_q);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 dsf = pack8(st, 8 * s2);
+#pragma unroll
+        for (int db = 0; db < C::DB; ++db) {
+          const bf16x8 a = load_tr_frag(Kl, KS, kb * 32 + 16 * s2, db * 32, lane);
+          dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, dsf, dq[db], 0, 0, 0);
+        }
+      }
+    }
+  }
+  const int q = q0 + lr;
+  if (q < N) store_T_tile<HD>(dqkv + (int64_t)(b * (int64_t)N + q) * ts + h * HD, dq, scale, h5);
+}
+
+}  // namespace
+
+static int check_attn(const void* qkv, int dtype, int64_t B, int64_t N, int64_t H, int64_t hd, const char* who) {
+  VITMI_REQUIRE(qkv && B > 0 && N > 0 && H > 0, VITMI_E_BADARG, "%s: null pointer or empty shape", who);
+  VITMI_REQUIRE(dtype == VITMI_BF16, VITMI_E_DTYPE, "%s: this kernel is bf16 (fp32 goes to vitmi_attn_*_f32 via dtype dispatch)", who);
+  VITMI_REQUIRE(hd == 32 || hd == 64, VITMI_E_SHAPE, "%s: head dim %lld not in {32, 64}", who, (long long)hd);
+  VITMI_REQUIRE(B * H <= 65535, VITMI_E_SHAPE, "%s: B*H = %lld exceeds the grid limit 65535", who, (long long)(B * H));
+  VITMI_REQUIRE(is_aligned(qkv, 16), VITMI_E_ALIGN, "%s: qkv must be 16-B aligned", who);
+  return 0;
+}
+
+int attn_fwd_f32(const float* qkv, float* out, float* lse, int64_t B, int64_t N, int64_t H, int64_t hd, float scale, hipStream_t stream);
+int attn_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int64_t B, int64_t N, int64_t H, int64_t hd, float scale, float* delta, hipStream_t stream);
+
+extern "C" int vitmi_attn_fwd(const void* qkv, void* out, float* lse, int dtype, int64_t B,
+                              int64_t N, int64_t H, int64_t hd, float scale, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  VITMI_REQUIRE(out && lse, VITMI_E_BADARG, "attn_fwd: null out/lse");
+  if (dtype == VITMI_F32) return attn_fwd_f32((const float*)qkv, (float*)out, lse, B, N, H, hd, scale, stream);
+  int rc = check_attn(qkv, dtype, B, N, H, hd, "attn_fwd");
+  if (rc) return rc;
+  VITMI_REQUIRE(is_aligned(out, 8), VITMI_E_ALIGN, "attn_fwd: out must be 8-B aligned");
+  dim3 grid((unsigned)((N + 127) / 128), (unsigned)(B * H));
+  if (hd == 64) {
+    const size_t lds = 64 * AttnCfg<64>::KS + 64 * AttnCfg<64>::VS;
+    hipLaunchKernelGGL((attn_fwd_kernel<64>), grid, dim3(256), lds, stream, (const bf16*)qkv, (bf16*)out, lse, (int)N, (int)H, scale * LOG2E);
+  } else {
+    const size_t lds = 64 * AttnCfg<32>::KS + 64 * AttnCfg<32>::VS;
+    hipLaunchKernelGGL((attn_fwd_kernel<32>), grid, dim3(256), lds, stream, (const bf16*)qkv, (bf16*)out, lse, (int)N, (int)H, scale * LOG2E);
+  }
+  return vitmi_check_launch("attn_fwd_kernel");
+}
+
+extern "C" size_t vitmi_attn_bwd_workspace(int64_t B, int64_t N, int64_t H) {
+  return (size_t)(B * N * H) * sizeof(float);
+}
+
+extern "C" int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+                              void* dqkv, int dtype, int64_t B, int64_t N, int64_t H, int64_t hd,
+                              float scale, void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  VITMI_REQUIRE(out && dout && lse && dqkv, VITMI_E_BADARG, "attn_bwd: null argument");
+  VITMI_REQUIRE(workspace && workspace_bytes >= vitmi_attn_bwd_workspace(B, N, H), VITMI_E_WORKSPACE, "attn_bwd: workspace too small");
+  float* delta = reinterpret_cast<float*>(workspace);
+  if (dtype == VITMI_F32)
+    return attn_bwd_f32((const float*)qkv, (const float*)out, (const float*)dout, lse, (float*)dqkv, B, N, H, hd, scale, delta, stream);
+  int rc = check_attn(qkv, dtype, B, N, H, hd, "attn_bwd");
+  if (rc) return rc;
+  VITMI_REQUIRE(is_aligned(out, 16) && is_aligned(dout, 16) && is_aligned(dqkv, 8), VITMI_E_ALIGN, "attn_bwd: out/dout must be 16-B, dqkv 8-B aligned");
+  const int64_t rows = B * N * H;
+  dim3 grid((unsigned)((N + 127) / 128), (unsigned)(B * H));
+#define LAUNCH_BWD(HDV)                                                                                  \
+  do {                                                                                                   \
+    const int64_t threads = rows * (HDV / 8);                                                            \
+    hipLaunchKernelGGL((attn_delta_kernel<HDV>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,  \
+                       stream, (const bf16*)out, (const bf16*)dout, delta, rows, (int)N, (int)H);        \
+    rc = vitmi_check_launch("attn_delta_kernel");                                                        \
+    if (rc) return rc;                                                                                   \
+    const size_t lds_a = 64 * AttnCfg<HDV>::KS + 64 * sizeof(float);                                     \
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HDV>), grid, dim3(256), lds_a, stream, (const bf16*)qkv,    \
+                       (const bf16*)dout, lse, delta, (bf16*)dqkv, (int)N, (int)H, scale, scale * LOG2E); \
+    rc = vitmi_check_launch("attn_bwd_dkdv_kernel");                                                     \
+    if (rc) return rc;                                                                                   \
+    const size_t lds_b = 128 * AttnCfg<HDV>::KS;                                                         \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<HDV>), grid, dim3(256), lds_b, stream, (const bf16*)qkv,      \
+                       (const bf16*)dout, lse, delta, (bf16*)dqkv, (int)N, (int)H, scale, scale * LOG2E); \
+    rc = vitmi_check_launch("attn_bwd_dq_kernel");                                                       \
+  } while (0)
+  if (hd == 64) LAUNCH_BWD(64); else LAUNCH_BWD(32);
+#undef LAUNCH_BWD
+  return rc;
+}

@@ -1,0 +1,84 @@
+// Shared device/host helpers for libvitmi (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "../../include/vitmi.h"
+
+typedef __bf16 bf16;
+typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+// ---- host-side error plumbing ------------------------------------------
+void vitmi_set_error(const std::string& s);
+int vitmi_fail(int code, const char* fmt, ...);
+int vitmi_check_launch(const char* what);
+
+#define VITMI_REQUIRE(cond, code, ...)                  \
+  do {                                                  \
+    if (!(cond)) return vitmi_fail((code), __VA_ARGS__); \
+  } while (0)
+
+static inline bool is_aligned(const void* p, size_t a) {
+  return (reinterpret_cast<uintptr_t>(p) % a) == 0;
+}
+static inline size_t dtype_size(int dt) { return dt == VITMI_BF16 ? 2 : 4; }
+
+// ---- device helpers ----------------------------------------------------
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// exact (erf) GELU and its derivative, as nn.GELU() default
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float dgelu_erf(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// 4-element vector load/store of T as fp32 (T=float: 16 B, T=bf16: 8 B)
+template <typename T> __device__ __forceinline__ f32x4 load4(const T* p);
+template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) {
+  return *reinterpret_cast<const f32x4*>(p);
+}
+template <> __device__ __forceinline__ f32x4 load4<bf16>(const bf16* p) {
+  bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+  f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  return r;
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void store4<float>(float* p, f32x4 v) {
+  *reinterpret_cast<f32x4*>(p) = v;
+}
+template <> __device__ __forceinline__ void store4<bf16>(bf16* p, f32x4 v) {
+  bf16x4 r = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+  *reinterpret_cast<bf16x4*>(p) = r;
+}
+
+// MFMA C/D layout of the 32x32 shapes: register r of lane l holds
+// row = (r&3) + 8*(r>>2) + 4*(l>>5), col = l&31   (guide §3)
+__device__ __forceinline__ int mfma32_row(int reg, int lane_hi) {
+  return (reg & 3) + 8 * (reg >> 2) + 4 * lane_hi;
+}

@@ -1,0 +1,286 @@
+// HBM-bound helpers of the path: dtype cast, patch gather (im2col), column
+// sums (bias / pos_embed gradients), softmax cross-entropy, SGD-momentum.
+// All grid-stride with 16-B vector accesses where alignment allows.
+#include "common.h"
+
+namespace {
+
+constexpr int EW_BLOCK = 256;
+inline unsigned ew_grid(int64_t work_items) {
+  int64_t b = (work_items + EW_BLOCK - 1) / EW_BLOCK;
+  const int64_t cap = 256 * 8;   // 8 blocks per CU
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+// ------------------------------------------------------------------ cast --
+template <typename TS, typename TD>
+__global__ void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n4 = n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+    store4<TD>(dst + i * 4, load4<TS>(src + i * 4));
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    dst[i] = from_f32<TD>(to_f32(src[i]));
+}
+
+// -------------------------------------------------------------- patchify --
+// one thread = 4 consecutive k of one output row (k = c*p*p + i*p + j; j runs
+// along W, so 4 consecutive j are contiguous in NCHW when p % 4 == 0)
+template <typename TD>
+__global__ void patchify_kernel(const float* __restrict__ x, int64_t sb, int64_t sc, int64_t sh,
+                                int64_t sw, TD* __restrict__ out, int64_t B, int C, int H, int W,
+                                int p, int cls_rows) {
+  const int gh = H / p, gw = W / p;
+  const int ntok = cls_rows + gh * gw;
+  const int Kp = C * p * p;
+  const int kq = Kp / 4;
+  const int64_t total = B * ntok * (int64_t)kq;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    const int k4 = (int)(idx % kq);
+    const int64_t row = idx / kq;
+    const int t = (int)(row % ntok);
+    const int64_t b = row / ntok;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (t >= cls_rows) {
+      const int pt = t - cls_rows;
+      const int py = pt / gw, px = pt % gw;
+      const int k = k4 * 4;
+      const int c = k / (p * p), rem = k % (p * p);
+      const int i = rem / p, j = rem % p;
+      const float* src = x + b * sb + c * sc + (int64_t)(py * p + i) * sh + (int64_t)(px * p + j) * sw;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = src[e * sw];
+    }
+    store4<TD>(out + row * Kp + k4 * 4, v);
+  }
+}
+
+// ---------------------------------------------------------------- colsum --
+// partial[s][n] = sum over rows r = s*4+w, step 4*S of x[r][n]
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, int64_t M,
+                                                             int64_t N, int64_t ld,
+                                                             float* __restrict__ part) {
+  __shared__ float red[4][64 * VEC];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t c0 = ((int64_t)blockIdx.x * 64 + lane) * VEC;
+  float acc[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+  if (c0 < N) {
+    for (int64_t r = (int64_t)blockIdx.y * 4 + w; r < M; r += (int64_t)gridDim.y * 4) {
+      if constexpr (VEC == 4) {
+        const f32x4 v = load4<T>(x + r * ld + c0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += v[e];
+      } else {
+        acc[0] += to_f32(x[r * ld + c0]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) red[w][lane * VEC + e] = acc[e];
+  __syncthreads();
+  if (w == 0 && c0 < N) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int i = lane * VEC + e;
+      part[(int64_t)blockIdx.y * N + c0 + e] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+    }
+  }
+}
+
+__global__ void colsum_final_kernel(const float* __restrict__ part, int S, int64_t N,
+                                    float* __restrict__ out) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  float s = 0.f;
+  for (int r = 0; r < S; ++r) s += part[(int64_t)r * N + c];
+  out[c] = s;
+}
+
+inline int colsum_splits(int64_t M) {
+  int64_t s = (M + 3) / 4;
+  return (int)(s < 128 ? s : 128);
+}
+
+// ------------------------------------------------------------------ xent --
+// one wave per sample; K classes strided over lanes
+__global__ __launch_bounds__(256) void xent_kernel(const float* __restrict__ logits,
+                                                   const int64_t* __restrict__ labels,
+                                                   float* __restrict__ loss_rows,
+                                                   float* __restrict__ dlogits,
+                                                   int32_t* __restrict__ correct_rows,
+                                                   int64_t B, int K) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t b = (int64_t)blockIdx.x * 4 + w;
+  if (b >= B) return;
+  const float* lr = logits + b * K;
+  float mx = -INFINITY;
+  int amax = 0;
+  for (int k = lane; k < K; k += 64) {
+    const float v = lr[k];
+    if (v > mx) { mx = v; amax = k; }     // first maximum within the lane
+  }
+  // wave argmax, ties -> lowest index (torch.argmax on CPU returns the first)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float om = __shfl_xor(mx, o);
+    const int oa = __shfl_xor(amax, o);
+    if (om > mx || (om == mx && oa < amax)) { mx = om; amax = oa; }
+  }
+  float se = 0.f;
+  for (int k = lane; k < K; k += 64) se += __expf(lr[k] - mx);
+  se = wave_sum(se);
+  const float lse = mx + __logf(se);
+  const int64_t lab = labels[b];
+  const float invB = 1.f / (float)B;
+  if (dlogits) {
+    for (int k = lane; k < K; k += 64) {
+      const float p = __expf(lr[k] - lse);
+      dlogits[b * K + k] = (p - (k == lab ? 1.f : 0.f)) * invB;
+    }
+  }
+  if (lane == 0) {
+    loss_rows[b] = lse - lr[lab];
+    correct_rows[b] = (amax == (int)lab) ? 1 : 0;
+  }
+}
+
+// deterministic final reduction of the per-sample losses (single block)
+__global__ __launch_bounds__(256) void xent_reduce_kernel(const float* __restrict__ loss_rows,
+                                                          const int32_t* __restrict__ correct_rows,
+                                                          float* __restrict__ loss,
+                                                          int32_t* __restrict__ correct, int64_t B) {
+  __shared__ float sl[256];
+  __shared__ int sc[256];
+  float l = 0.f;
+  int c = 0;
+  for (int64_t i = threadIdx.x; i < B; i += 256) { l += loss_rows[i]; c += correct_rows[i]; }
+  sl[threadIdx.x] = l; sc[threadIdx.x] = c;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { sl[threadIdx.x] += sl[threadIdx.x + o]; sc[threadIdx.x] += sc[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { loss[0] = sl[0] / (float)B; if (correct) correct[0] = sc[0]; }
+}
+
+// ------------------------------------------------------------------- sgd --
+__global__ void sgd_momentum_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                    float* __restrict__ buf, bf16* __restrict__ shadow, int64_t n,
+                                    float lr, float momentum, float gscale) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n4 = n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i * 4);
+    f32x4 bv = *reinterpret_cast<f32x4*>(buf + i * 4);
+    f32x4 pv = *reinterpret_cast<f32x4*>(p + i * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      bv[e] = momentum * bv[e] + gscale * gv[e];
+      pv[e] = pv[e] - lr * bv[e];
+    }
+    *reinterpret_cast<f32x4*>(buf + i * 4) = bv;
+    *reinterpret_cast<f32x4*>(p + i * 4) = pv;
+    if (shadow) store4<bf16>(shadow + i * 4, pv);
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float b = momentum * buf[i] + gscale * g[i];
+    buf[i] = b;
+    const float pn = p[i] - lr * b;
+    p[i] = pn;
+    if (shadow) shadow[i] = (bf16)pn;
+  }
+}
+
+}  // namespace
+
+extern "C" int vitmi_cast(const void* src, int sd, void* dst, int dd, int64_t n, void* stream_) {
+  VITMI_REQUIRE(src && dst && n > 0, VITMI_E_BADARG, "cast: null pointer or n <= 0");
+  VITMI_REQUIRE(is_aligned(src, 4 * dtype_size(sd)) && is_aligned(dst, 4 * dtype_size(dd)), VITMI_E_ALIGN, "cast: pointers must be 4-element aligned");
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const unsigned grid = ew_grid(n / 4 + 1);
+  if (sd == VITMI_F32 && dd == VITMI_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16>), dim3(grid), dim3(EW_BLOCK), 0, stream, (const float*)src, (bf16*)dst, n);
+  else if (sd == VITMI_BF16 && dd == VITMI_F32) hipLaunchKernelGGL((cast_kernel<bf16, float>), dim3(grid), dim3(EW_BLOCK), 0, stream, (const bf16*)src, (float*)dst, n);
+  else if (sd == VITMI_F32 && dd == VITMI_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(EW_BLOCK), 0, stream, (const float*)src, (float*)dst, n);
+  else if (sd == VITMI_BF16 && dd == VITMI_BF16) hipLaunchKernelGGL((cast_kernel<bf16, bf16>), dim3(grid), dim3(EW_BLOCK), 0, stream, (const bf16*)src, (bf16*)dst, n);
+  else return vitmi_fail(VITMI_E_DTYPE, "cast: bad dtypes %d -> %d", sd, dd);
+  return vitmi_check_launch("cast_kernel");
+}
+
+extern "C" int vitmi_patchify(const float* x, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                              void* out, int out_dtype, int64_t B, int64_t C, int64_t H, int64_t W,
+                              int64_t p, int cls_rows, void* stream_) {
+  VITMI_REQUIRE(x && out && B > 0 && C > 0 && H > 0 && W > 0 && p > 0, VITMI_E_BADARG, "patchify: null pointer or empty shape");
+  VITMI_REQUIRE(H % p == 0 && W % p == 0, VITMI_E_SHAPE, "patchify: image %lldx%lld not divisible by patch %lld", (long long)H, (long long)W, (long long)p);
+  VITMI_REQUIRE(p % 4 == 0, VITMI_E_SHAPE, "patchify: patch size must be a multiple of 4");
+  VITMI_REQUIRE(cls_rows == 0 || cls_rows == 1, VITMI_E_BADARG, "patchify: cls_rows must be 0 or 1");
+  VITMI_REQUIRE(is_aligned(out, 4 * dtype_size(out_dtype)), VITMI_E_ALIGN, "patchify: out alignment");
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const int64_t ntok = cls_rows + (H / p) * (W / p);
+  const int64_t total = B * ntok * (C * p * p / 4);
+  const unsigned grid = ew_grid(total);
+  if (out_dtype == VITMI_BF16)
+    hipLaunchKernelGGL((patchify_kernel<bf16>), dim3(grid), dim3(EW_BLOCK), 0, stream, x, sb, sc, sh, sw, (bf16*)out, B, (int)C, (int)H, (int)W, (int)p, cls_rows);
+  else if (out_dtype == VITMI_F32)
+    hipLaunchKernelGGL((patchify_kernel<float>), dim3(grid), dim3(EW_BLOCK), 0, stream, x, sb, sc, sh, sw, (float*)out, B, (int)C, (int)H, (int)W, (int)p, cls_rows);
+  else return vitmi_fail(VITMI_E_DTYPE, "patchify: bad out dtype");
+  return vitmi_check_launch("patchify_kernel");
+}
+
+extern "C" size_t vitmi_colsum_workspace(int64_t M, int64_t N) {
+  return (size_t)colsum_splits(M) * (size_t)N * sizeof(float);
+}
+
+extern "C" int vitmi_colsum(const void* x, int dtype, int64_t M, int64_t N, int64_t ld, float* out,
+                            void* workspace, size_t workspace_bytes, void* stream_) {
+  VITMI_REQUIRE(x && out && M > 0 && N > 0 && ld >= N, VITMI_E_BADARG, "colsum: bad argument");
+  VITMI_REQUIRE(workspace && workspace_bytes >= vitmi_colsum_workspace(M, N), VITMI_E_WORKSPACE, "colsum: workspace too small");
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const int S = colsum_splits(M);
+  float* part = reinterpret_cast<float*>(workspace);
+  const bool vec = (N % 4 == 0) && (ld % 4 == 0) && is_aligned(x, 4 * dtype_size(dtype));
+  const int cols_per_block = vec ? 256 : 64;
+  dim3 grid((unsigned)((N + cols_per_block - 1) / cols_per_block), (unsigned)S);
+  if (dtype == VITMI_BF16) {
+    if (vec) hipLaunchKernelGGL((colsum_partial_kernel<bf16, 4>), grid, dim3(256), 0, stream, (const bf16*)x, M, N, ld, part);
+    else hipLaunchKernelGGL((colsum_partial_kernel<bf16, 1>), grid, dim3(256), 0, stream, (const bf16*)x, M, N, ld, part);
+  } else if (dtype == VITMI_F32) {
+    if (vec) hipLaunchKernelGGL((colsum_partial_kernel<float, 4>), grid, dim3(256), 0, stream, (const float*)x, M, N, ld, part);
+    else hipLaunchKernelGGL((colsum_partial_kernel<float, 1>), grid, dim3(256), 0, stream, (const float*)x, M, N, ld, part);
+  } else return vitmi_fail(VITMI_E_DTYPE, "colsum: bad dtype");
+  int rc = vitmi_check_launch("colsum_partial_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, part, S, N, out);
+  return vitmi_check_launch("colsum_final_kernel");
+}
+
+extern "C" int vitmi_softmax_xent(const float* logits, const int64_t* labels, float* loss,
+                                  float* dlogits, int32_t* correct, int64_t B, int64_t K,
+                                  void* stream_) {
+  VITMI_REQUIRE(logits && labels && loss && B > 0 && K > 0, VITMI_E_BADARG, "softmax_xent: bad argument");
+  VITMI_REQUIRE(dlogits, VITMI_E_BADARG, "softmax_xent: dlogits buffer required (its tail is used as scratch)");
+  // scratch: per-sample loss / correct live behind the caller's loss pointer?
+  // No: keep the ABI allocation-free by requiring loss to have room for 1+B
+  // floats and correct for 1+B ints (documented in INTEGRATION.md).
+  VITMI_REQUIRE(correct, VITMI_E_BADARG, "softmax_xent: correct buffer required");
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  hipLaunchKernelGGL(xent_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, logits, labels, loss + 1, dlogits, correct + 1, B, (int)K);
+  int rc = vitmi_check_launch("xent_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(xent_reduce_kernel, dim3(1), dim3(256), 0, stream, loss + 1, correct + 1, loss, correct, B);
+  return vitmi_check_launch("xent_reduce_kernel");
+}
+
+extern "C" int vitmi_sgd_momentum(float* p, const float* g, float* buf, void* shadow, int64_t n,
+                                  float lr, float momentum, float grad_scale, void* stream_) {
+  VITMI_REQUIRE(p && g && buf && n > 0, VITMI_E_BADARG, "sgd_momentum: bad argument");
+  VITMI_REQUIRE(is_aligned(p, 16) && is_aligned(g, 16) && is_aligned(buf, 16) && (!shadow || is_aligned(shadow, 8)), VITMI_E_ALIGN, "sgd_momentum: buffers must be 16-B aligned");
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  hipLaunchKernelGGL(sgd_momentum_kernel, dim3(ew_grid(n / 4 + 1)), dim3(EW_BLOCK), 0, stream, p, g, buf, (bf16*)shadow, n, lr, momentum, grad_scale);
+  return vitmi_check_launch("sgd_momentum_kernel");
+}

@@ -1,0 +1,83 @@
+// GEMM epilogues shared by the generic and the fast kernels (include/vitmi.h
+// VITMI_EPI_*).  All arithmetic in fp32; one rounding at the store.
+#pragma once
+#include "common.h"
+
+struct EpiArgs {
+  int mode;
+  void* C; int64_t ldc; int c_bf16;
+  void* C2; int64_t ldc2;
+  const float* bias;
+  const void* R; int64_t ldr; int r_bf16;
+  const float* gamma;
+  const void* AUX; int64_t ldaux; int aux_bf16;
+  const float* pos; int64_t n_tok; int64_t ldpos; const float* cls;
+  float alpha;
+  int accumulate;
+};
+
+struct GemmArgs {
+  int64_t M, N, K;
+  const void* A; int64_t lda; int a_km;
+  const void* B; int64_t ldb; int b_km;
+  EpiArgs e;
+};
+
+__device__ __forceinline__ float ld_any(const void* p, int64_t i, int is_bf16) {
+  return is_bf16 ? (float)reinterpret_cast<const bf16*>(p)[i]
+                 : reinterpret_cast<const float*>(p)[i];
+}
+__device__ __forceinline__ void st_any(void* p, int64_t i, int is_bf16, float v) {
+  if (is_bf16) reinterpret_cast<bf16*>(p)[i] = (bf16)v;
+  else reinterpret_cast<float*>(p)[i] = v;
+}
+
+// value-level epilogue: returns the value to store in C; *v2 = value for C2
+template <int MODE>
+__device__ __forceinline__ float epi_value(const EpiArgs& e, int64_t m, int64_t n, float acc,
+                                           float* v2) {
+  if constexpr (MODE == VITMI_EPI_STORE) {
+    float v = acc * e.alpha;
+    if (e.bias) v += e.bias[n];
+    if (e.accumulate) v += reinterpret_cast<const float*>(e.C)[m * e.ldc + n];
+    return v;
+  } else if constexpr (MODE == VITMI_EPI_BIAS_GELU) {
+    float pre = acc + (e.bias ? e.bias[n] : 0.f);
+    // the backward pass differentiates at the STORED pre-activation, so
+    // round it first when C2 is bf16 (keeps fwd and bwd consistent)
+    if (e.c_bf16) pre = (float)(bf16)pre;
+    *v2 = pre;
+    return gelu_erf(pre);
+  } else if constexpr (MODE == VITMI_EPI_RESIDUAL) {
+    float v = acc + (e.bias ? e.bias[n] : 0.f);
+    if (e.gamma) v *= e.gamma[n];
+    return ld_any(e.R, m * e.ldr + n, e.r_bf16) + v;
+  } else if constexpr (MODE == VITMI_EPI_DGELU) {
+    return acc * dgelu_erf(ld_any(e.AUX, m * e.ldaux + n, e.aux_bf16));
+  } else {  // VITMI_EPI_PATCH_POS
+    const int64_t t = m % e.n_tok;
+    if (t == 0 && e.cls) return e.cls[n] + e.pos[n];
+    return acc + (e.bias ? e.bias[n] : 0.f) + e.pos[t * e.ldpos + n];
+  }
+}
+
+// scalar store of one output element (generic kernel)
+template <int MODE>
+__device__ __forceinline__ void epi_store1(const EpiArgs& e, int64_t m, int64_t n, float acc) {
+  float v2 = 0.f;
+  const float v = epi_value<MODE>(e, m, n, acc, &v2);
+  st_any(e.C, m * e.ldc + n, e.c_bf16, v);
+  if constexpr (MODE == VITMI_EPI_BIAS_GELU) {
+    if (e.C2) st_any(e.C2, m * e.ldc2 + n, e.c_bf16, v2);
+  }
+}
+
+__device__ __forceinline__ void epi_store1_rt(const EpiArgs& e, int64_t m, int64_t n, float acc) {
+  switch (e.mode) {
+    case VITMI_EPI_STORE: epi_store1<VITMI_EPI_STORE>(e, m, n, acc); break;
+    case VITMI_EPI_BIAS_GELU: epi_store1<VITMI_EPI_BIAS_GELU>(e, m, n, acc); break;
+    case VITMI_EPI_RESIDUAL: epi_store1<VITMI_EPI_RESIDUAL>(e, m, n, acc); break;
+    case VITMI_EPI_DGELU: epi_store1<VITMI_EPI_DGELU>(e, m, n, acc); break;
+    default: epi_store1<VITMI_EPI_PATCH_POS>(e, m, n, acc); break;
+  }
+}

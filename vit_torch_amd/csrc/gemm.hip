@@ -1,0 +1,162 @@
+// vitmi_gemm: argument checking, dispatch, and the GENERIC strided MFMA kernel.
+//
+// The generic kernel takes any M/N/K, any strides and both operand
+// orientations, for bf16 (v_mfma_f32_32x32x16_bf16) and fp32
+// (v_mfma_f32_32x32x2_f32: exact fp32 fma chain in k order — the parity mode).
+// It is the correctness workhorse (classifier head, ragged shapes, fp32 mode);
+// the aligned hot shapes go to gemm_fast.hip.
+#include "epilogue.h"
+
+bool gemm_fast_supported(const GemmArgs& g, int in_bf16);
+int gemm_fast_launch(const GemmArgs& g, hipStream_t stream);
+
+namespace {
+
+constexpr int GBM = 64, GBN = 64, GBK = 32;
+
+template <typename T> struct GenericTraits;
+template <> struct GenericTraits<bf16> { static constexpr int LDK = 40; };   // 80-B rows
+template <> struct GenericTraits<float> { static constexpr int LDK = 33; };
+
+// stage a [64 rows][32 k] tile of op(X) into LDS as [row][k], zero-filling
+// everything outside (rows_total, K)
+template <typename T>
+__device__ __forceinline__ void stage_tile(T* lds, const T* X, int64_t ld, int kmajor,
+                                           int64_t row0, int64_t rows_total, int64_t k0,
+                                           int64_t K, int tid) {
+  constexpr int LDK = GenericTraits<T>::LDK;
+#pragma unroll
+  for (int i = 0; i < (GBM * GBK) / 256; ++i) {
+    const int idx = tid + i * 256;
+    int r, kk;
+    if (kmajor) { r = idx >> 5; kk = idx & 31; }   // consecutive lanes walk k
+    else        { r = idx & 63; kk = idx >> 6; }   // consecutive lanes walk rows
+    const int64_t gr = row0 + r, gk = k0 + kk;
+    T v = from_f32<T>(0.f);
+    if (gr < rows_total && gk < K) v = kmajor ? X[gr * ld + gk] : X[gk * ld + gr];
+    lds[r * LDK + kk] = v;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs g) {
+  constexpr int LDK = GenericTraits<T>::LDK;
+  __shared__ __attribute__((aligned(16))) T As[GBM * LDK];
+  __shared__ __attribute__((aligned(16))) T Bs[GBN * LDK];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.y * GBM, n0 = (int64_t)blockIdx.x * GBN;
+  const T* A = reinterpret_cast<const T*>(g.A);
+  const T* B = reinterpret_cast<const T*>(g.B);
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+  for (int64_t k0 = 0; k0 < g.K; k0 += GBK) {
+    stage_tile<T>(As, A, g.lda, g.a_km, m0, g.M, k0, g.K, tid);
+    stage_tile<T>(Bs, B, g.ldb, g.b_km, n0, g.N, k0, g.K, tid);
+    __syncthreads();
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(&As[(wm * 32 + lr) * LDK + s * 16 + 8 * lh]);
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(&Bs[(wn * 32 + lr) * LDK + s * 16 + 8 * lh]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const float a = As[(wm * 32 + lr) * LDK + 2 * s + lh];
+        const float b = Bs[(wn * 32 + lr) * LDK + 2 * s + lh];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  const int64_t n = n0 + wn * 32 + lr;
+  if (n >= g.N) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t m = m0 + wm * 32 + mfma32_row(r, lh);
+    if (m < g.M) epi_store1_rt(g.e, m, n, acc[r]);
+  }
+}
+
+}  // namespace
+
+static int build_args(const vitmi_gemm_desc* d, GemmArgs* out) {
+  VITMI_REQUIRE(d, VITMI_E_BADARG, "gemm: null descriptor");
+  VITMI_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, VITMI_E_BADARG, "gemm: M,N,K must be > 0 (got %lld,%lld,%lld)",
+                (long long)d->M, (long long)d->N, (long long)d->K);
+  VITMI_REQUIRE(d->A && d->B && d->C, VITMI_E_BADARG, "gemm: A, B, C must be non-null");
+  VITMI_REQUIRE(d->in_dtype == VITMI_F32 || d->in_dtype == VITMI_BF16, VITMI_E_DTYPE, "gemm: bad in_dtype %d", d->in_dtype);
+  VITMI_REQUIRE(d->c_dtype == VITMI_F32 || d->c_dtype == VITMI_BF16, VITMI_E_DTYPE, "gemm: bad c_dtype %d", d->c_dtype);
+  VITMI_REQUIRE(d->epilogue >= VITMI_EPI_STORE && d->epilogue <= VITMI_EPI_PATCH_POS, VITMI_E_BADARG, "gemm: bad epilogue %d", d->epilogue);
+  VITMI_REQUIRE(d->lda >= (d->a_kmajor ? d->K : d->M), VITMI_E_BADARG, "gemm: lda too small");
+  VITMI_REQUIRE(d->ldb >= (d->b_kmajor ? d->K : d->N), VITMI_E_BADARG, "gemm: ldb too small");
+  VITMI_REQUIRE(d->ldc >= d->N, VITMI_E_BADARG, "gemm: ldc too small");
+  GemmArgs g;
+  g.M = d->M; g.N = d->N; g.K = d->K;
+  g.A = d->A; g.lda = d->lda; g.a_km = d->a_kmajor ? 1 : 0;
+  g.B = d->B; g.ldb = d->ldb; g.b_km = d->b_kmajor ? 1 : 0;
+  EpiArgs& e = g.e;
+  e.mode = d->epilogue;
+  e.C = d->C; e.ldc = d->ldc; e.c_bf16 = d->c_dtype == VITMI_BF16;
+  e.C2 = d->C2; e.ldc2 = d->ldc2;
+  e.bias = d->bias;
+  e.R = d->R; e.ldr = d->ldr; e.r_bf16 = d->r_dtype == VITMI_BF16;
+  e.gamma = d->gamma;
+  e.AUX = d->AUX; e.ldaux = d->ldaux; e.aux_bf16 = d->in_dtype == VITMI_BF16;
+  e.pos = d->pos; e.n_tok = d->n_tok; e.ldpos = d->N; e.cls = d->cls;
+  e.alpha = d->alpha == 0.f ? 1.f : d->alpha;
+  e.accumulate = d->accumulate;
+  switch (d->epilogue) {
+    case VITMI_EPI_STORE:
+      VITMI_REQUIRE(!d->accumulate || d->c_dtype == VITMI_F32, VITMI_E_DTYPE, "gemm: accumulate needs an fp32 C");
+      break;
+    case VITMI_EPI_BIAS_GELU:
+      VITMI_REQUIRE(!d->C2 || d->ldc2 >= d->N, VITMI_E_BADARG, "gemm: ldc2 too small");
+      break;
+    case VITMI_EPI_RESIDUAL:
+      VITMI_REQUIRE(d->R && d->ldr >= d->N, VITMI_E_BADARG, "gemm: EPI_RESIDUAL needs R with ldr >= N");
+      VITMI_REQUIRE(d->r_dtype == d->c_dtype, VITMI_E_DTYPE, "gemm: EPI_RESIDUAL needs r_dtype == c_dtype");
+      break;
+    case VITMI_EPI_DGELU:
+      VITMI_REQUIRE(d->AUX && d->ldaux >= d->N, VITMI_E_BADARG, "gemm: EPI_DGELU needs AUX with ldaux >= N");
+      break;
+    case VITMI_EPI_PATCH_POS:
+      VITMI_REQUIRE(d->pos && d->n_tok > 0, VITMI_E_BADARG, "gemm: EPI_PATCH_POS needs pos and n_tok");
+      break;
+  }
+  *out = g;
+  return 0;
+}
+
+extern "C" int vitmi_gemm_uses_fast(const vitmi_gemm_desc* d) {
+  GemmArgs g;
+  if (build_args(d, &g) != 0) return 0;
+  if (d->impl == VITMI_GEMM_GENERIC) return 0;
+  return gemm_fast_supported(g, d->in_dtype == VITMI_BF16) ? 1 : 0;
+}
+
+extern "C" int vitmi_gemm(const vitmi_gemm_desc* d, void* stream_) {
+  GemmArgs g;
+  int rc = build_args(d, &g);
+  if (rc) return rc;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const bool in_bf16 = d->in_dtype == VITMI_BF16;
+  const bool fast_ok = gemm_fast_supported(g, in_bf16);
+  if (d->impl == VITMI_GEMM_FAST)
+    VITMI_REQUIRE(fast_ok, VITMI_E_SHAPE, "gemm: VITMI_GEMM_FAST requested but shape/dtype/alignment unsupported (M=%lld N=%lld K=%lld)",
+                  (long long)d->M, (long long)d->N, (long long)d->K);
+  if (fast_ok && d->impl != VITMI_GEMM_GENERIC) return gemm_fast_launch(g, stream);
+
+  dim3 grid((unsigned)((g.N + GBN - 1) / GBN), (unsigned)((g.M + GBM - 1) / GBM));
+  VITMI_REQUIRE(grid.y <= 65535u, VITMI_E_SHAPE, "gemm: M too large for the generic kernel grid");
+  if (in_bf16) hipLaunchKernelGGL(gemm_generic_kernel<bf16>, grid, dim3(256), 0, stream, g);
+  else hipLaunchKernelGGL(gemm_generic_kernel<float>, grid, dim3(256), 0, stream, g);
+  return vitmi_check_launch("gemm_generic_kernel");
+}

@@ -1,0 +1,235 @@
+// LayerNorm forward / backward: one wavefront per row, row held in registers,
+// fp32 statistics, 16-B (fp32) / 8-B (bf16) vector accesses.  HBM-bound:
+// fwd moves (sizeof(X)+sizeof(Y))*D bytes per row, bwd
+// (sizeof(dY)+sizeof(X)+2*sizeof(G)+sizeof(Gb))*D.
+#include "common.h"
+
+namespace {
+
+constexpr int LN_MAXV = 8;   // float4 chunks per lane -> D <= 8*64*4 = 2048
+
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, int64_t xs,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta,
+                                                     TY* __restrict__ y, int64_t ys,
+                                                     float* __restrict__ mean_out,
+                                                     float* __restrict__ rstd_out,
+                                                     int64_t M, int D, float eps) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + w;
+  if (row >= M) return;
+  const TX* xr = x + row * xs;
+  f32x4 v[LN_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < D) {
+      v[i] = load4<TX>(xr + c);
+      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < D) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+    }
+  }
+  const float var = wave_sum(q) / (float)D;
+  const float rstd = rsqrtf(var + eps);
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+  TY* yr = y + row * ys;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < D) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
+      store4<TY>(yr + c, o);
+    }
+  }
+}
+
+// Backward.  Each wave walks rows row0, row0+stride, ...; dgamma/dbeta are kept
+// per lane in registers, reduced over the block's 4 waves through LDS and
+// written as one partial row per block: part[blockIdx][0..D) = dgamma,
+// part[blockIdx][D..2D) = dbeta.  A second kernel sums the partial rows.
+template <typename TDY, typename TX, typename TG, typename TGB>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy, int64_t dys,
+                                                     const TX* __restrict__ x, int64_t xs,
+                                                     const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma,
+                                                     const TG* g_in, TG* g_out, int64_t gs,
+                                                     TGB* __restrict__ gb_out, int64_t gbs,
+                                                     float* __restrict__ part,
+                                                     int64_t M, int D) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [4][D]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  f32x4 gam[LN_MAXV], dg[LN_MAXV], db[LN_MAXV];
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    dg[i] = z; db[i] = z; gam[i] = z;
+    if (c < D) gam[i] = *reinterpret_cast<const f32x4*>(gamma + c);
+  }
+  const float invD = 1.f / (float)D;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < M; row += (int64_t)gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    const TDY* dyr = dy + row * dys;
+    const TX* xr = x + row * xs;
+    f32x4 xh[LN_MAXV], dv[LN_MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < D) {
+        const f32x4 xv = load4<TX>(xr + c);
+        dv[i] = load4<TDY>(dyr + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          xh[i][j] = (xv[j] - mu) * rs;
+          dg[i][j] += dv[i][j] * xh[i][j];
+          db[i][j] += dv[i][j];
+          dv[i][j] *= gam[i][j];          // dy * gamma
+          s1 += dv[i][j];
+          s2 += dv[i][j] * xh[i][j];
+        }
+      }
+    }
+    const float c1 = wave_sum(s1) * invD, c2 = wave_sum(s2) * invD;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < D) {
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = rs * (dv[i][j] - c1 - xh[i][j] * c2);
+        if (g_in) {
+          const f32x4 gi = load4<TG>(g_in + row * gs + c);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] += gi[j];
+        }
+        store4<TG>(g_out + row * gs + c, o);
+        if (gb_out) store4<TGB>(gb_out + row * gbs + c, o);
+      }
+    }
+  }
+  // block reduction of dgamma then dbeta
+  float* prow = part + (int64_t)blockIdx.x * 2 * D;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < D) *reinterpret_cast<f32x4*>(red + w * D + c) = pass == 0 ? dg[i] : db[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256)
+      prow[pass * D + c] = (red[c] + red[D + c]) + (red[2 * D + c] + red[3 * D + c]);
+    __syncthreads();
+  }
+}
+
+__global__ void ln_bwd_reduce_kernel(const float* __restrict__ part, int nrows, int D,
+                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= 2 * D) return;
+  float s = 0.f;
+  for (int r = 0; r < nrows; ++r) s += part[(int64_t)r * 2 * D + c];
+  if (c < D) dgamma[c] = s; else dbeta[c - D] = s;
+}
+
+inline int ln_bwd_blocks(int64_t M) {
+  int64_t b = (M + 3) / 4;
+  return (int)(b < 512 ? b : 512);
+}
+
+}  // namespace
+
+static int check_ln_common(const void* x, int x_dtype, int64_t x_stride, int64_t M, int64_t D, const char* who) {
+  VITMI_REQUIRE(x && M > 0 && D > 0, VITMI_E_BADARG, "%s: null input or empty shape", who);
+  VITMI_REQUIRE(D % 4 == 0 && D <= LN_MAXV * 256, VITMI_E_SHAPE, "%s: D=%lld must be a multiple of 4 and <= %d", who, (long long)D, LN_MAXV * 256);
+  VITMI_REQUIRE(x_stride % 4 == 0 && is_aligned(x, 4 * dtype_size(x_dtype)), VITMI_E_ALIGN, "%s: rows must be 4-element aligned", who);
+  return 0;
+}
+
+extern "C" int vitmi_layernorm_fwd(const void* x, int x_dtype, int64_t x_stride, const float* gamma,
+                                   const float* beta, void* y, int y_dtype, int64_t y_stride,
+                                   float* mean, float* rstd, int64_t M, int64_t D, float eps,
+                                   void* stream_) {
+  int rc = check_ln_common(x, x_dtype, x_stride, M, D, "layernorm_fwd");
+  if (rc) return rc;
+  VITMI_REQUIRE(y && gamma && beta, VITMI_E_BADARG, "layernorm_fwd: null y/gamma/beta");
+  VITMI_REQUIRE(y_stride % 4 == 0 && is_aligned(y, 4 * dtype_size(y_dtype)) && is_aligned(gamma, 16) && is_aligned(beta, 16),
+                VITMI_E_ALIGN, "layernorm_fwd: y/gamma/beta alignment");
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  dim3 grid((unsigned)((M + 3) / 4)), block(256);
+#define LN_FWD(TX, TY)                                                                        \
+  hipLaunchKernelGGL((ln_fwd_kernel<TX, TY>), grid, block, 0, stream, (const TX*)x, x_stride, \
+                     gamma, beta, (TY*)y, y_stride, mean, rstd, M, (int)D, eps)
+  if (x_dtype == VITMI_F32 && y_dtype == VITMI_F32) LN_FWD(float, float);
+  else if (x_dtype == VITMI_F32 && y_dtype == VITMI_BF16) LN_FWD(float, bf16);
+  else if (x_dtype == VITMI_BF16 && y_dtype == VITMI_BF16) LN_FWD(bf16, bf16);
+  else if (x_dtype == VITMI_BF16 && y_dtype == VITMI_F32) LN_FWD(bf16, float);
+  else return vitmi_fail(VITMI_E_DTYPE, "layernorm_fwd: dtype combination");
+#undef LN_FWD
+  return vitmi_check_launch("ln_fwd_kernel");
+}
+
+extern "C" size_t vitmi_layernorm_bwd_workspace(int64_t M, int64_t D) {
+  return (size_t)ln_bwd_blocks(M) * 2 * (size_t)D * sizeof(float);
+}
+
+extern "C" int vitmi_layernorm_bwd(const void* dy, int dy_dtype, int64_t dy_stride, const void* x,
+                                   int x_dtype, int64_t x_stride, const float* mean,
+                                   const float* rstd, const float* gamma, const void* g_in,
+                                   void* g_out, int g_dtype, int64_t g_stride, void* gb_out,
+                                   int gb_dtype, int64_t gb_stride, float* dgamma, float* dbeta,
+                                   int64_t M, int64_t D, void* workspace, size_t workspace_bytes,
+                                   void* stream_) {
+  int rc = check_ln_common(x, x_dtype, x_stride, M, D, "layernorm_bwd");
+  if (rc) return rc;
+  VITMI_REQUIRE(dy && mean && rstd && gamma && g_out && dgamma && dbeta, VITMI_E_BADARG, "layernorm_bwd: null argument");
+  VITMI_REQUIRE(dy_stride % 4 == 0 && g_stride % 4 == 0 && (!gb_out || gb_stride % 4 == 0), VITMI_E_ALIGN, "layernorm_bwd: strides must be multiples of 4");
+  VITMI_REQUIRE(is_aligned(dy, 4 * dtype_size(dy_dtype)) && is_aligned(g_out, 4 * dtype_size(g_dtype)) &&
+                    (!g_in || is_aligned(g_in, 4 * dtype_size(g_dtype))) &&
+                    (!gb_out || is_aligned(gb_out, 4 * dtype_size(gb_dtype))) && is_aligned(gamma, 16),
+                VITMI_E_ALIGN, "layernorm_bwd: pointer alignment");
+  VITMI_REQUIRE(workspace && workspace_bytes >= vitmi_layernorm_bwd_workspace(M, D), VITMI_E_WORKSPACE, "layernorm_bwd: workspace too small");
+  VITMI_REQUIRE(is_aligned(workspace, 16), VITMI_E_ALIGN, "layernorm_bwd: workspace alignment");
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const int nblk = ln_bwd_blocks(M);
+  const size_t lds = 4 * (size_t)D * sizeof(float);
+  float* part = reinterpret_cast<float*>(workspace);
+  // activation dtype T (dy, gb) and residual dtype R (x, g) combinations built:
+  //   (T,R) = (f32,f32), (bf16,f32), (bf16,bf16)
+#define LN_BWD(TDY, TX, TG, TGB)                                                               \
+  hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TG, TGB>), dim3(nblk), dim3(256), lds, stream,    \
+                     (const TDY*)dy, dy_stride, (const TX*)x, x_stride, mean, rstd, gamma,     \
+                     (const TG*)g_in, (TG*)g_out, g_stride, (TGB*)gb_out, gb_stride, part, M, (int)D)
+  const int gbd = gb_out ? gb_dtype : dy_dtype;
+  if (dy_dtype == VITMI_F32 && x_dtype == VITMI_F32 && g_dtype == VITMI_F32 && gbd == VITMI_F32) LN_BWD(float, float, float, float);
+  else if (dy_dtype == VITMI_BF16 && x_dtype == VITMI_F32 && g_dtype == VITMI_F32 && gbd == VITMI_BF16) LN_BWD(bf16, float, float, bf16);
+  else if (dy_dtype == VITMI_BF16 && x_dtype == VITMI_BF16 && g_dtype == VITMI_BF16 && gbd == VITMI_BF16) LN_BWD(bf16, bf16, bf16, bf16);
+  else if (dy_dtype == VITMI_F32 && x_dtype == VITMI_BF16 && g_dtype == VITMI_BF16 && gbd == VITMI_F32) LN_BWD(float, bf16, bf16, float);
+  else return vitmi_fail(VITMI_E_DTYPE, "layernorm_bwd: dtype combination (dy=%d x=%d g=%d gb=%d)", dy_dtype, x_dtype, g_dtype, gbd);
+#undef LN_BWD
+  rc = vitmi_check_launch("ln_bwd_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((2 * D + 255) / 256)), dim3(256), 0, stream,
+                     part, nblk, (int)D, dgamma, dbeta);
+  return vitmi_check_launch("ln_bwd_reduce_kernel");
+}

@@ -1,0 +1,216 @@
+"""Tensor-level wrappers over the C ABI (include/vitmi.h).
+
+PyTorch is used here only for device memory and the current HIP stream; every
+function enqueues hand-written HIP kernels from libvitmi.so and nothing else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (BF16, EPI_BIAS_GELU, EPI_DGELU, EPI_PATCH_POS, EPI_RESIDUAL, EPI_STORE, F32,
+                   GEMM_AUTO, GEMM_FAST, GEMM_GENERIC, GemmDesc, check, load)
+
+_WS: dict = {}
+
+
+def dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float32:
+        return F32
+    raise TypeError(f"vitmi: unsupported dtype {t.dtype}")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.VitmiError("vitmi ops run on the GPU only (tensor is on %s); there is no CPU fallback" % t.device)
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only scratch buffer per (device, stream)."""
+    key = (str(device), _stream())
+    w = _WS.get(key)
+    if w is None or w.numel() < nbytes:
+        w = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = w
+    return w
+
+
+def gemm(A, B, C_out, *, a_kmajor=True, b_kmajor=True, epilogue=EPI_STORE, bias=None, R=None,
+         gamma=None, aux=None, C2=None, pos=None, n_tok=0, cls=None, alpha=1.0, accumulate=False,
+         impl=GEMM_AUTO):
+    """C = epilogue(op(A) @ op(B)^T); see vitmi_gemm in include/vitmi.h."""
+    _need_cuda(A, B, C_out)
+    assert A.dim() == 2 and B.dim() == 2 and C_out.dim() == 2
+    assert A.stride(1) == 1 and B.stride(1) == 1 and C_out.stride(1) == 1
+    M, K = (A.shape if a_kmajor else (A.shape[1], A.shape[0]))
+    N, Kb = (B.shape if b_kmajor else (B.shape[1], B.shape[0]))
+    assert K == Kb, f"gemm: K mismatch {K} vs {Kb}"
+    assert tuple(C_out.shape) == (M, N), f"gemm: C shape {tuple(C_out.shape)} != {(M, N)}"
+    assert A.dtype == B.dtype
+    d = GemmDesc()
+    d.M, d.N, d.K = M, N, K
+    d.A, d.lda, d.a_kmajor = A.data_ptr(), A.stride(0), int(a_kmajor)
+    d.B, d.ldb, d.b_kmajor = B.data_ptr(), B.stride(0), int(b_kmajor)
+    d.in_dtype = dtype_code(A)
+    d.epilogue = epilogue
+    d.C, d.ldc, d.c_dtype = C_out.data_ptr(), C_out.stride(0), dtype_code(C_out)
+    if C2 is not None:
+        assert C2.dtype == C_out.dtype and tuple(C2.shape) == (M, N) and C2.stride(1) == 1
+        d.C2, d.ldc2 = C2.data_ptr(), C2.stride(0)
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
+        d.bias = bias.data_ptr()
+    if R is not None:
+        assert tuple(R.shape) == (M, N) and R.stride(1) == 1
+        d.R, d.ldr, d.r_dtype = R.data_ptr(), R.stride(0), dtype_code(R)
+    if gamma is not None:
+        assert gamma.dtype == torch.float32 and gamma.numel() == N and gamma.is_contiguous()
+        d.gamma = gamma.data_ptr()
+    if aux is not None:
+        assert aux.dtype == A.dtype and tuple(aux.shape) == (M, N) and aux.stride(1) == 1
+        d.AUX, d.ldaux = aux.data_ptr(), aux.stride(0)
+    if pos is not None:
+        assert pos.dtype == torch.float32 and pos.is_contiguous() and pos.numel() == n_tok * N
+        d.pos, d.n_tok = pos.data_ptr(), n_tok
+    if cls is not None:
+        assert cls.dtype == torch.float32 and cls.numel() == N and cls.is_contiguous()
+        d.cls = cls.data_ptr()
+    d.alpha = float(alpha)
+    d.accumulate = int(accumulate)
+    d.impl = impl
+    check(load().vitmi_gemm(C.byref(d), _stream()), "vitmi_gemm")
+    return C_out
+
+
+def gemm_uses_fast(M, N, K, *, a_kmajor=True, b_kmajor=True, in_dtype=BF16, c_dtype=BF16,
+                   epilogue=EPI_STORE, lda=None, ldb=None, ldc=None) -> bool:
+    """Host-only query (no GPU needed): would this problem take the fast kernel?"""
+    d = GemmDesc()
+    d.M, d.N, d.K = M, N, K
+    d.A = d.B = d.C = 256  # any non-null, 256-B aligned address
+    d.R = d.AUX = d.pos = 256
+    d.lda = lda or (K if a_kmajor else M)
+    d.ldb = ldb or (K if b_kmajor else N)
+    d.ldc = ldc or N
+    d.ldr = d.ldaux = N
+    d.n_tok = 1
+    d.a_kmajor, d.b_kmajor = int(a_kmajor), int(b_kmajor)
+    d.in_dtype, d.c_dtype, d.r_dtype, d.epilogue = in_dtype, c_dtype, c_dtype, epilogue
+    return bool(load().vitmi_gemm_uses_fast(C.byref(d)))
+
+
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps, *, M=None, D=None, x_stride=None, y_stride=None):
+    """Rows of x (stride x_stride elements) -> y; mean/rstd fp32 [M] (may be None)."""
+    _need_cuda(x, y)
+    D = D or x.shape[-1]
+    M = M or x.numel() // D
+    xs = x_stride if x_stride is not None else D
+    ys = y_stride if y_stride is not None else D
+    check(load().vitmi_layernorm_fwd(x.data_ptr(), dtype_code(x), xs, gamma.data_ptr(), beta.data_ptr(),
+                                     y.data_ptr(), dtype_code(y), ys, _ptr(mean), _ptr(rstd),
+                                     M, D, float(eps), _stream()), "vitmi_layernorm_fwd")
+    return y
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, g_in, g_out, gb_out, dgamma, dbeta, *, M=None, D=None,
+                  dy_stride=None, x_stride=None, g_stride=None, gb_stride=None):
+    _need_cuda(dy, x, g_out)
+    D = D or x.shape[-1]
+    M = M or dy.numel() // D
+    lib = load()
+    nbytes = lib.vitmi_layernorm_bwd_workspace(M, D)
+    ws = workspace(nbytes, dy.device)
+    check(lib.vitmi_layernorm_bwd(
+        dy.data_ptr(), dtype_code(dy), dy_stride if dy_stride is not None else D,
+        x.data_ptr(), dtype_code(x), x_stride if x_stride is not None else D,
+        mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+        _ptr(g_in), g_out.data_ptr(), dtype_code(g_out), g_stride if g_stride is not None else D,
+        _ptr(gb_out), dtype_code(gb_out) if gb_out is not None else dtype_code(dy),
+        gb_stride if gb_stride is not None else D,
+        dgamma.data_ptr(), dbeta.data_ptr(), M, D, ws.data_ptr(), ws.numel(), _stream()),
+        "vitmi_layernorm_bwd")
+
+
+def attn_fwd(qkv, out, lse, B, N, H, hd, scale):
+    _need_cuda(qkv, out, lse)
+    assert qkv.is_contiguous() and out.is_contiguous() and lse.dtype == torch.float32
+    check(load().vitmi_attn_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), dtype_code(qkv),
+                                B, N, H, hd, float(scale), _stream()), "vitmi_attn_fwd")
+    return out
+
+
+def attn_bwd(qkv, out, dout, lse, dqkv, B, N, H, hd, scale):
+    _need_cuda(qkv, out, dout, dqkv)
+    assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and dqkv.is_contiguous()
+    lib = load()
+    ws = workspace(lib.vitmi_attn_bwd_workspace(B, N, H), qkv.device)
+    check(lib.vitmi_attn_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
+                             dqkv.data_ptr(), dtype_code(qkv), B, N, H, hd, float(scale),
+                             ws.data_ptr(), ws.numel(), _stream()), "vitmi_attn_bwd")
+    return dqkv
+
+
+def cast(src, dst):
+    _need_cuda(src, dst)
+    assert src.numel() == dst.numel() and src.is_contiguous() and dst.is_contiguous()
+    check(load().vitmi_cast(src.data_ptr(), dtype_code(src), dst.data_ptr(), dtype_code(dst),
+                            src.numel(), _stream()), "vitmi_cast")
+    return dst
+
+
+def patchify(x, out, p, cls_rows):
+    """x [B,C,H,W] fp32 (any strides) -> out [B*(cls_rows+gh*gw), C*p*p]."""
+    _need_cuda(x, out)
+    assert x.dtype == torch.float32 and x.dim() == 4 and out.is_contiguous()
+    B, Cc, H, W = x.shape
+    sb, sc, sh, sw = x.stride()
+    check(load().vitmi_patchify(x.data_ptr(), sb, sc, sh, sw, out.data_ptr(), dtype_code(out),
+                                B, Cc, H, W, p, int(cls_rows), _stream()), "vitmi_patchify")
+    return out
+
+
+def colsum(x, out, *, M=None, N=None, ld=None):
+    _need_cuda(x, out)
+    N = N or x.shape[-1]
+    M = M or x.numel() // N
+    ld = ld or N
+    assert out.dtype == torch.float32 and out.numel() >= N
+    lib = load()
+    ws = workspace(lib.vitmi_colsum_workspace(M, N), x.device)
+    check(lib.vitmi_colsum(x.data_ptr(), dtype_code(x), M, N, ld, out.data_ptr(), ws.data_ptr(),
+                           ws.numel(), _stream()), "vitmi_colsum")
+    return out
+
+
+def softmax_xent(logits, labels, loss_buf, dlogits, correct_buf):
+    """loss_buf fp32 [1+B] (loss_buf[0] = mean loss), correct_buf int32 [1+B]."""
+    _need_cuda(logits, labels, loss_buf, dlogits, correct_buf)
+    B, K = logits.shape
+    assert logits.dtype == torch.float32 and logits.is_contiguous() and labels.dtype == torch.int64
+    assert loss_buf.numel() >= 1 + B and correct_buf.numel() >= 1 + B and correct_buf.dtype == torch.int32
+    check(load().vitmi_softmax_xent(logits.data_ptr(), labels.data_ptr(), loss_buf.data_ptr(),
+                                    dlogits.data_ptr(), correct_buf.data_ptr(), B, K, _stream()),
+          "vitmi_softmax_xent")
+
+
+def sgd_momentum(p, g, buf, shadow, lr, momentum, grad_scale=1.0):
+    _need_cuda(p, g, buf)
+    assert p.dtype == g.dtype == buf.dtype == torch.float32
+    assert p.numel() == g.numel() == buf.numel()
+    check(load().vitmi_sgd_momentum(p.data_ptr(), g.data_ptr(), buf.data_ptr(), _ptr(shadow),
+                                    p.numel(), float(lr), float(momentum), float(grad_scale),
+                                    _stream()), "vitmi_sgd_momentum")

@@ -1,0 +1,404 @@
+"""DINO-style VisionTransformer whose forward/backward run on libvitmi HIP kernels.
+
+Drop-in for the module the reference obtains from
+`torch.hub.load('facebookresearch/dino:main', arch)`
+(/root/reference/models/vision_all.py:156): same constructor arguments,
+attribute surface (`.patch_embed.proj` Conv2d, `.norm`, `.head`, `.blocks[i]`),
+parameter names/shapes (state-dict compatible) and call contract
+`model(x[B,C,H,W] fp32) -> [B, K or D] fp32` (utils_network.py:418).
+
+The nn.Linear / nn.LayerNorm / nn.Conv2d sub-modules are parameter holders
+only; `forward` hands the whole network to `VitEngine`, which sequences the
+hand-written kernels (GEMM+epilogues, LayerNorm, fused attention, ...) through
+the C ABI and implements the backward pass explicitly (the reference relies on
+autograd, utils_network.py:441).  There is no PyTorch fallback.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from ._lib import (EPI_BIAS_GELU, EPI_DGELU, EPI_PATCH_POS, EPI_RESIDUAL, EPI_STORE, GEMM_AUTO,
+                   VitmiError)
+from .packing import ParamPack
+
+_DT = {"bf16": torch.bfloat16, "fp32": torch.float32, torch.bfloat16: torch.bfloat16,
+       torch.float32: torch.float32}
+
+
+# ----------------------------------------------------------------- modules --
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(hidden_features, in_features)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads, qkv_bias):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio, qkv_bias, eps):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=eps)
+        self.attn = Attention(dim, num_heads, qkv_bias)
+        self.norm2 = nn.LayerNorm(dim, eps=eps)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, img_size, patch_size, in_chans, embed_dim):
+        super().__init__()
+        self.img_size = img_size
+        self.patch_size = patch_size
+        self.num_patches = (img_size // patch_size) ** 2
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+
+def _trunc_normal_(t, std=0.02):
+    return nn.init.trunc_normal_(t, std=std)
+
+
+class VisionTransformer(nn.Module):
+    """`apply_head=False` reproduces upstream DINO, whose forward returns
+    norm(x)[:, 0] and never calls `.head` ([recall]); the factory
+    passes `apply_head=True` when it installs a classifier."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=0, embed_dim=768,
+                 depth=12, num_heads=12, mlp_ratio=4.0, qkv_bias=True, eps=1e-6, apply_head=False,
+                 compute_dtype="bf16", residual_dtype="fp32", **_ignored):
+        super().__init__()
+        self.num_features = self.embed_dim = embed_dim
+        self.apply_head = apply_head
+        self.compute_dtype = _DT[compute_dtype]
+        self.residual_dtype = _DT[residual_dtype]
+        self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.patch_embed.num_patches + 1, embed_dim))
+        self.blocks = nn.ModuleList([Block(embed_dim, num_heads, mlp_ratio, qkv_bias, eps)
+                                     for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=eps)
+        self.head = nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()
+        _trunc_normal_(self.pos_embed)
+        _trunc_normal_(self.cls_token)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                _trunc_normal_(m.weight)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.LayerNorm):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+        self._engine: Optional[VitEngine] = None
+
+    def engine(self) -> "VitEngine":
+        if self._engine is None or not self._engine.is_current():
+            self._engine = VitEngine(self)
+        return self._engine
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise VitmiError("vit_torch_amd models run on an MI355X (HIP) device; got a CPU tensor "
+                             "and there is no CPU fallback")
+        eng = self.engine()
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in eng.pack.params)
+        if need_grad:
+            return _EngineFn.apply(eng, x, *eng.pack.params)
+        return eng.forward(x, save=False)
+
+
+class _EngineFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, x, *params):
+        ctx.eng = eng
+        return eng.forward(x, save=True)
+
+    @staticmethod
+    def backward(ctx, dout):
+        eng = ctx.eng
+        eng.backward(dout)
+        grads = []
+        for p, gv in zip(eng.pack.params, eng.pack.fresh_grad_views()):
+            if not p.requires_grad:
+                grads.append(None)
+            elif p.grad is not None and p.grad.data_ptr() == gv.data_ptr():
+                grads.append(None)      # .grad already IS this buffer (zero_grad(set_to_none=False))
+            else:
+                grads.append(gv)
+        return (None, None, *grads)
+
+
+# ------------------------------------------------------------------ engine --
+def _head_layers(head) -> Optional[List[tuple]]:
+    """[(Linear, gelu_after)] for Identity / Linear / Sequential(Linear[,GELU]...) heads
+    (/root/reference/models/vision_all.py:299-320); None if the head is something else."""
+    if isinstance(head, nn.Identity):
+        return []
+    if isinstance(head, nn.Linear):
+        return [(head, False)]
+    if isinstance(head, nn.Sequential):
+        out = []
+        mods = list(head)
+        i = 0
+        while i < len(mods):
+            if not isinstance(mods[i], nn.Linear):
+                return None
+            gelu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.GELU)
+            out.append((mods[i], gelu))
+            i += 2 if gelu else 1
+        return out
+    return None
+
+
+class VitEngine:
+    """Executes VisionTransformer forward / backward as a fixed kernel sequence.
+
+    Activations of type T (compute dtype: bf16, or fp32 in parity mode), residual
+    stream of type R; every residual update writes a NEW buffer, so the inputs of
+    every LayerNorm are kept for backward without an extra copy.
+    """
+
+    def __init__(self, model: VisionTransformer):
+        self.model = model
+        dev = model.pos_embed.device
+        if dev.type != "cuda":
+            raise VitmiError("move the model to the GPU before the first forward")
+        self.T = model.compute_dtype
+        self.R = model.residual_dtype
+        if self.T == torch.float32 and self.R != torch.float32:
+            raise VitmiError("fp32 compute needs an fp32 residual stream")
+        self.head = _head_layers(model.head) if model.apply_head else []
+        if self.head is None:
+            raise VitmiError("head must be Identity, Linear or Sequential(Linear[, GELU], ...)")
+        named = [(n, p) for n, p in model.named_parameters()]
+        self.pack = ParamPack(named, dev, shadow=self.T == torch.bfloat16)
+        self.saved = None
+        self.gemm_impl = GEMM_AUTO
+
+    def is_current(self) -> bool:
+        m = self.model
+        return (self.pack.is_current() and m.compute_dtype == self.T and m.residual_dtype == self.R
+                and len(self.pack.params) == sum(1 for _ in m.parameters()))
+
+    # -- helpers -------------------------------------------------------------
+    def _w(self, p):
+        return self.pack.w(p)
+
+    def _gemm(self, *a, **k):
+        return ops.gemm(*a, impl=self.gemm_impl, **k)
+
+    def _pos_for(self, gh, gw):
+        """pos_embed at the input's patch grid: as stored, or the bicubic resize
+        upstream DINO applies ([recall]); returns (pos [N,D] fp32, graph or None)."""
+        m = self.model
+        pos = self.pack.f32(m.pos_embed)
+        n_stored = pos.shape[1] - 1
+        if gh * gw == n_stored and gh == gw:
+            return pos.reshape(-1, pos.shape[-1]), None
+        side = int(math.sqrt(n_stored))
+        D = pos.shape[-1]
+        leaf = pos.detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            patch = leaf[:, 1:].reshape(1, side, side, D).permute(0, 3, 1, 2)
+            patch = F.interpolate(patch, scale_factor=((gh + 0.1) / side, (gw + 0.1) / side),
+                                  mode="bicubic")
+            assert patch.shape[-2] == gh and patch.shape[-1] == gw
+            eff = torch.cat((leaf[:, :1], patch.permute(0, 2, 3, 1).reshape(1, -1, D)), dim=1)
+            eff = eff.reshape(-1, D).contiguous()
+        return eff.detach(), (leaf, eff)
+
+    # -- forward -------------------------------------------------------------
+    def forward(self, x, save: bool):
+        m, T, R = self.model, self.T, self.R
+        dev = x.device
+        x = x.float() if x.dtype != torch.float32 else x
+        B, Cin, Himg, Wimg = x.shape
+        p = m.patch_embed.patch_size
+        conv = m.patch_embed.proj
+        if Cin != conv.in_channels:
+            raise VitmiError(f"input has {Cin} channels, patch_embed.proj expects {conv.in_channels}")
+        gh, gw = Himg // p, Wimg // p
+        N = 1 + gh * gw
+        M = B * N
+        D = m.embed_dim
+        H = m.blocks[0].attn.num_heads
+        hd = D // H
+        Kp = Cin * p * p
+        if self.pack.shadow is not None:
+            ops.cast(self.pack.flat, self.pack.shadow)
+
+        def new(rows, cols, dt):
+            return torch.empty((rows, cols), dtype=dt, device=dev)
+
+        patches = new(M, Kp, T)
+        ops.patchify(x, patches, p, cls_rows=1)
+        pos, pos_graph = self._pos_for(gh, gw)
+        X = new(M, D, R)
+        self._gemm(patches, self._w(conv.weight).view(D, Kp), X, epilogue=EPI_PATCH_POS,
+                   bias=self.pack.f32(conv.bias) if conv.bias is not None else None,
+                   pos=pos, n_tok=N, cls=self.pack.f32(m.cls_token).view(-1))
+        blocks = []
+        for blk in m.blocks:
+            a, mlp = blk.attn, blk.mlp
+            ln1 = new(M, D, T)
+            mean1 = torch.empty(M, dtype=torch.float32, device=dev)
+            rstd1 = torch.empty(M, dtype=torch.float32, device=dev)
+            ops.layernorm_fwd(X, self.pack.f32(blk.norm1.weight), self.pack.f32(blk.norm1.bias), ln1,
+                              mean1, rstd1, blk.norm1.eps, M=M, D=D)
+            qkv = new(M, 3 * D, T)
+            self._gemm(ln1, self._w(a.qkv.weight), qkv,
+                       bias=self.pack.f32(a.qkv.bias) if a.qkv.bias is not None else None)
+            O = new(M, D, T)
+            lse = torch.empty(B * H * N, dtype=torch.float32, device=dev)
+            ops.attn_fwd(qkv, O, lse, B, N, H, hd, a.scale)
+            X1 = new(M, D, R)
+            self._gemm(O, self._w(a.proj.weight), X1, epilogue=EPI_RESIDUAL,
+                       bias=self.pack.f32(a.proj.bias), R=X)
+            ln2 = new(M, D, T)
+            mean2 = torch.empty(M, dtype=torch.float32, device=dev)
+            rstd2 = torch.empty(M, dtype=torch.float32, device=dev)
+            ops.layernorm_fwd(X1, self.pack.f32(blk.norm2.weight), self.pack.f32(blk.norm2.bias), ln2,
+                              mean2, rstd2, blk.norm2.eps, M=M, D=D)
+            Dh = mlp.fc1.out_features
+            pre = new(M, Dh, T)
+            hid = new(M, Dh, T)
+            self._gemm(ln2, self._w(mlp.fc1.weight), hid, epilogue=EPI_BIAS_GELU,
+                       bias=self.pack.f32(mlp.fc1.bias), C2=pre)
+            X2 = new(M, D, R)
+            self._gemm(hid, self._w(mlp.fc2.weight), X2, epilogue=EPI_RESIDUAL,
+                       bias=self.pack.f32(mlp.fc2.bias), R=X1)
+            if save:
+                blocks.append((X, ln1, mean1, rstd1, qkv, O, lse, X1, ln2, mean2, rstd2, pre, hid))
+            X = X2
+        feat = torch.empty((B, D), dtype=torch.float32, device=dev)
+        meanf = torch.empty(B, dtype=torch.float32, device=dev)
+        rstdf = torch.empty(B, dtype=torch.float32, device=dev)
+        ops.layernorm_fwd(X, self.pack.f32(m.norm.weight), self.pack.f32(m.norm.bias), feat, meanf,
+                          rstdf, m.norm.eps, M=B, D=D, x_stride=N * D, y_stride=D)
+        # classifier head: tiny fp32 GEMMs on the generic MFMA kernel
+        acts = [feat]
+        pres = []
+        cur = feat
+        for lin, gelu in self.head:
+            out = torch.empty((B, lin.out_features), dtype=torch.float32, device=dev)
+            bias = self.pack.f32(lin.bias) if lin.bias is not None else None
+            if gelu:
+                pre_h = torch.empty_like(out)
+                ops.gemm(cur, self.pack.f32(lin.weight), out, epilogue=EPI_BIAS_GELU, bias=bias, C2=pre_h)
+                pres.append(pre_h)
+            else:
+                ops.gemm(cur, self.pack.f32(lin.weight), out, bias=bias)
+                pres.append(None)
+            acts.append(out)
+            cur = out
+        if save:
+            self.saved = dict(B=B, N=N, M=M, D=D, H=H, hd=hd, Kp=Kp, patches=patches, blocks=blocks,
+                              Xf=X, meanf=meanf, rstdf=rstdf, acts=acts, pres=pres,
+                              pos_graph=pos_graph)
+        return cur
+
+    # -- backward ------------------------------------------------------------
+    def backward(self, dout):
+        s = self.saved
+        if s is None:
+            raise VitmiError("backward called without a saved forward (or called twice)")
+        self.saved = None
+        m, T, R, pk = self.model, self.T, self.R, self.pack
+        B, N, M, D, H, hd = s["B"], s["N"], s["M"], s["D"], s["H"], s["hd"]
+        dev = dout.device
+        d = dout.contiguous().float()
+
+        def new(rows, cols, dt):
+            return torch.empty((rows, cols), dtype=dt, device=dev)
+
+        # ---- classifier head (fp32, generic MFMA kernel) ----
+        # z_i = a_i W_i^T + b_i ; a_{i+1} = gelu(z_i) or z_i.  `d` is dL/dz_i on entry;
+        # the inner layer's gelu' is applied by the DGELU epilogue of this layer's dX GEMM.
+        acts, pres = s["acts"], s["pres"]
+        if self.head and self.head[-1][1]:
+            raise VitmiError("a head ending in GELU is not supported")
+        for li in range(len(self.head) - 1, -1, -1):
+            lin, _ = self.head[li]
+            ops.gemm(d, acts[li], pk.g(lin.weight), a_kmajor=False, b_kmajor=False)
+            if lin.bias is not None:
+                ops.colsum(d, pk.g(lin.bias))
+            dx = torch.empty((B, lin.in_features), dtype=torch.float32, device=dev)
+            if li > 0 and self.head[li - 1][1]:
+                ops.gemm(d, pk.f32(lin.weight), dx, b_kmajor=False, epilogue=EPI_DGELU, aux=pres[li - 1])
+            else:
+                ops.gemm(d, pk.f32(lin.weight), dx, b_kmajor=False)
+            d = dx
+        dfeat = d
+
+        # ---- final LayerNorm on the CLS rows -> residual-stream gradient G ----
+        G = torch.zeros((M, D), dtype=R, device=dev)
+        ops.layernorm_bwd(dfeat, s["Xf"], s["meanf"], s["rstdf"], pk.f32(m.norm.weight), None, G, None,
+                          pk.g(m.norm.weight), pk.g(m.norm.bias), M=B, D=D,
+                          dy_stride=D, x_stride=N * D, g_stride=N * D)
+        if T == R:
+            Gb = G                      # GEMM operand and residual gradient share one buffer
+        else:
+            Gb = new(M, D, T)
+            ops.cast(G, Gb)
+        gb_out = None if T == R else Gb
+
+        saved_blocks = s["blocks"]
+        for blk in reversed(m.blocks):
+            sv = saved_blocks.pop()      # release each block's activations as we go
+            X, ln1, mean1, rstd1, qkv, O, lse, X1, ln2, mean2, rstd2, pre, hid = sv
+            del sv
+            a, mlp = blk.attn, blk.mlp
+            Dh = mlp.fc1.out_features
+            # MLP branch
+            dH = new(M, Dh, T)
+            self._gemm(Gb, self._w(mlp.fc2.weight), dH, b_kmajor=False, epilogue=EPI_DGELU, aux=pre)
+            self._gemm(Gb, hid, pk.g(mlp.fc2.weight), a_kmajor=False, b_kmajor=False)
+            ops.colsum(Gb, pk.g(mlp.fc2.bias))
+            dln2 = new(M, D, T)
+            self._gemm(dH, self._w(mlp.fc1.weight), dln2, b_kmajor=False)
+            self._gemm(dH, ln2, pk.g(mlp.fc1.weight), a_kmajor=False, b_kmajor=False)
+            ops.colsum(dH, pk.g(mlp.fc1.bias))
+            ops.layernorm_bwd(dln2, X1, mean2, rstd2, pk.f32(blk.norm2.weight), G, G, gb_out,
+                              pk.g(blk.norm2.weight), pk.g(blk.norm2.bias), M=M, D=D)
+            # attention branch
+            dO = new(M, D, T)
+            self._gemm(Gb, self._w(a.proj.weight), dO, b_kmajor=False)
+            self._gemm(Gb, O, pk.g(a.proj.weight), a_kmajor=False, b_kmajor=False)
+            ops.colsum(Gb, pk.g(a.proj.bias))
+            dqkv = new(M, 3 * D, T)
+            ops.attn_bwd(qkv, O, dO, lse, dqkv, B, N, H, hd, a.scale)
+            dln1 = new(M, D, T)
+            self._gemm(dqkv, self._w(a.qkv.weight), dln1, b_kmajor=False)
+            self._gemm(dqkv, ln1, pk.g(a.qkv.weight), a_kmajor=False, b_kmajor=False)
+            if a.qkv.bias is not None:
+                ops.colsum(dqkv, pk.g(a.qkv.bias))
+            ops.layernorm_bwd(dln1, X, mean1, rstd1, pk.f32(blk.norm1.weight), G, G, gb_out,
+                              pk.g(blk.norm1.weight), pk.g(blk.norm1.bias), M=M, D=D)
+
+        # ---- embeddings ----
+        conv = m.patch_embed.proj
+        Kp = s["Kp"]
+        dpos = torch.empty(N * D, dtype=torch.float32, device=dev)
+        ops.colsum(G, dpos, M=B, N=N * D, ld=N * D)          # sum over the batch
+        ops.cast(dpos[:D], pk.g(m.cls_token).view(-1))       # d cls = d pos[0]
+        if s["pos_graph"] is None:
+            ops.cast(dpos, pk.g(m.pos_embed).view(-1))
+        else:   # through the bicubic resize (parameter-only, once per step)
+            leaf, eff = s["pos_graph"]
+            (gleaf,) = torch.autograd.grad(eff, leaf, dpos.view_as(eff))
+            pk.g(m.pos_embed).copy_(gleaf)
+        self._gemm(Gb, s["patches"], pk.g(conv.weight).view(D, Kp), a_kmajor=False, b_kmajor=False)
+        if conv.bias is not None:
+            ops.colsum(dpos[D:].view(N - 1, D), pk.g(conv.bias))  # CLS rows carry no conv bias
