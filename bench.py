@@ -1,0 +1,188 @@
+#!/usr/bin/env python
+"""Headline benchmark (BASELINE.json): images/sec of the ViT-B/16 224x224 training step
+(forward + cross-entropy + backward + SGD-momentum step), 256 images per GPU, bf16
+MFMA operands / fp32 accumulation, synthetic data resident in HBM, random-init weights.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  Extra objects on it:
+  roofline     the GEMM kernel family (gemm_fast_kernel: >99 % of the step's FLOPs):
+               algorithmic FLOPs of every GEMM launch of one step / the sum of their
+               durations, measured with HIP events on the launch stream in an
+               instrumented step run right after the timed region.
+  cpu_baseline the oracle (plain PyTorch fp32 restatement of the reference model and
+               step) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2516.6          # 256 CU x 2.4 GHz x 4096 FLOP/CU/clk
+GFLOP_PER_IMAGE = 105.38           # ViT-B/16 @224 fwd+bwd
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--arch", default="dino_vitb16")
+    ap.add_argument("--img", type=int, default=224)
+    ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--residual", default="fp32", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(arch, img, batch, steps):
+    """Oracle timed on the host cores (test infrastructure used as the CPU baseline)."""
+    import torch.nn.functional as F
+    from oracle import vit_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    model = vit_ref.build(arch, classifier=10, img_size=img)
+    vit_ref.seeded_init_(model, 1)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9)
+    g = torch.Generator("cpu").manual_seed(0)
+    x = torch.randn(batch, 3, img, img, generator=g)
+    y = torch.randint(0, 10, (batch,), generator=g)
+
+    def step():
+        opt.zero_grad()
+        F.cross_entropy(model(x), y).backward()
+        opt.step()
+
+    step()                                   # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = time.perf_counter() - t0
+    return {"value": round(batch * steps / dt, 3), "unit": "images/sec", "cores": cores,
+            "threads": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} steps of {arch} fwd+CE+bwd+SGD at batch {batch}, {img}x{img}, fp32, after 1 warm-up"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} needs a torch.distributed.run launch with {a.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from vit_torch_amd import CrossEntropyLoss, FusedSGD, VisionModelZoo
+    from vit_torch_amd.ddp import GradReducer
+
+    torch.manual_seed(1)
+    model = VisionModelZoo.get_model(a.arch, pretrained=False, classifier=10, img_size=a.img,
+                                     compute_dtype=a.compute, residual_dtype=a.residual).to(dev)
+    g = torch.Generator("cpu").manual_seed(1000 + rank)     # per-rank shard of the global batch
+    x = torch.randn(a.batch, 3, a.img, a.img, generator=g).to(dev)
+    y = torch.randint(0, 10, (a.batch,), generator=g).to(dev)
+    crit = CrossEntropyLoss()
+    eng = model.engine()
+    reducer = GradReducer(eng.pack) if world > 1 else None
+    if reducer is not None:
+        reducer.broadcast_parameters(0)
+        eng.reducer = reducer
+    opt = FusedSGD(model.parameters(), lr=1e-3, momentum=0.9, grad_scale=1.0 / world)
+
+    def step():
+        opt.zero_grad()
+        loss = crit(model(x), y)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    loss_value = float(loss.item())
+
+    # ---- instrumented step: per-launch GEMM durations (HIP events, launch stream) ----
+    roof = None
+    if rank == 0:
+        eng.profile = []
+        step()
+        torch.cuda.synchronize()
+        rows = {}
+        for name, shape, flops, e0, e1 in eng.profile:
+            r = rows.setdefault((name, shape), [0, 0.0, 0.0])
+            r[0] += 1
+            r[1] += flops
+            r[2] += e0.elapsed_time(e1) * 1e-3
+        eng.profile = None
+        tot_f = sum(r[1] for r in rows.values())
+        tot_t = sum(r[2] for r in rows.values())
+        n_launch = sum(r[0] for r in rows.values())
+        ach = tot_f / tot_t / 1e12
+        roof = {"bound": "mfma", "kernel": "gemm_fast_kernel (all GEMM launches of one step)",
+                "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "launches_per_step": n_launch, "avg_launch_ms": round(tot_t / n_launch * 1e3, 4),
+                "gemm_ms_per_step": round(tot_t * 1e3, 3),
+                "by_shape": [{"kernel": k[0], "MNK": list(k[1]), "launches": v[0],
+                              "avg_ms": round(v[2] / v[0] * 1e3, 4),
+                              "tflops": round(v[1] / v[2] / 1e12, 1)} for k, v in sorted(rows.items())]}
+
+    cpu = None
+    if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.arch, a.img, a.cpu_batch, a.cpu_steps)
+
+    if rank == 0:
+        ips = a.batch * world * a.steps / elapsed
+        flop_img = GFLOP_PER_IMAGE if (a.arch == "dino_vitb16" and a.img == 224) else None
+        out = {
+            "metric": "images/sec fwd+bwd ViT-B/16 224^2 bs=256/GPU",
+            "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.compute, "data": "synthetic",
+            "config": {"workload": f"{a.arch} {a.img}x{a.img} fwd+CE+bwd+SGD(momentum) step, "
+                                   f"batch {a.batch}/GPU, 10 classes, random-init weights",
+                       "global_batch": a.batch * world, "residual_stream": a.residual,
+                       "parallelism": f"dp{world}"},
+            "loss": round(loss_value, 5),
+            "step_mfma_frac": (round(ips / world * flop_img * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4)
+                               if flop_img else None),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -58,3 +58,23 @@ def test_cpu_tensor_is_refused():
     m = VisionTransformer(img_size=32, patch_size=16, embed_dim=64, depth=1, num_heads=1)
     with pytest.raises(VitmiError):
         m(torch.zeros(1, 3, 32, 32))
+
+
+def test_hot_shapes_take_the_fast_gemm(lib):
+    """ViT-B/16, 256 images x 197 tokens: every large GEMM of the step
+    must be eligible for the LDS-DMA kernel, in all three orientations."""
+    from vit_torch_amd import ops
+    from vit_torch_amd._lib import BF16, EPI_BIAS_GELU, EPI_DGELU, EPI_PATCH_POS, EPI_RESIDUAL, F32
+    M, D = 256 * 197, 768
+    assert ops.gemm_uses_fast(M, 3 * D, D)                                           # qkv
+    assert ops.gemm_uses_fast(M, D, D, epilogue=EPI_RESIDUAL, c_dtype=F32)           # proj
+    assert ops.gemm_uses_fast(M, 4 * D, D, epilogue=EPI_BIAS_GELU)                   # fc1
+    assert ops.gemm_uses_fast(M, D, 4 * D, epilogue=EPI_RESIDUAL, c_dtype=F32)       # fc2
+    assert ops.gemm_uses_fast(M, D, D, epilogue=EPI_PATCH_POS, c_dtype=F32)          # patch embed
+    assert ops.gemm_uses_fast(M, 4 * D, D, b_kmajor=False, epilogue=EPI_DGELU)       # fc2 dgrad
+    assert ops.gemm_uses_fast(M, D, 3 * D, b_kmajor=False)                           # qkv dgrad
+    assert ops.gemm_uses_fast(3 * D, D, M, a_kmajor=False, b_kmajor=False, c_dtype=F32)   # qkv wgrad
+    assert ops.gemm_uses_fast(D, 4 * D, M, a_kmajor=False, b_kmajor=False, c_dtype=F32)   # fc2 wgrad
+    # ragged shapes and fp32 operands go to the generic kernel
+    assert not ops.gemm_uses_fast(256, 10, D, in_dtype=F32, c_dtype=F32)
+    assert not ops.gemm_uses_fast(640, 384, 384)

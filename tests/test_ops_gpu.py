@@ -318,3 +318,88 @@ def test_sgd_momentum_two_steps_match_torch(ops):
         ops.sgd_momentum(p, dev(g), buf, shadow, 0.01, 0.9)
     assert_close("sgd.p", p, ref.data, 1e-6)
     assert torch.equal(shadow.cpu(), p.cpu().to(torch.bfloat16))
+
+
+# ------------------------------------------------------------- fast gemm ---
+FAST_SHAPES = [(256, 256, 64), (512, 768, 768), (768, 512, 1024), (1024, 256, 128)]
+
+
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("M,N,K", FAST_SHAPES)
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_gemm_fast_layouts(ops, layout, M, N, K, cdt):
+    from vit_torch_amd._lib import GEMM_FAST
+    akm, bkm = {"nt": (True, True), "nn": (True, False), "tn": (False, False)}[layout]
+    a, b = bf16_round(gen((M, K), 1)), bf16_round(gen((N, K), 2))
+    want = a @ b.t()
+    A = dev(a if akm else a.t().contiguous(), torch.bfloat16)
+    B = dev(b if bkm else b.t().contiguous(), torch.bfloat16)
+    C = torch.full((M, N), float("nan"), device="cuda").to(cdt)
+    ops.gemm(A, B, C, a_kmajor=akm, b_kmajor=bkm, impl=GEMM_FAST)
+    assert_close(f"gemm_fast[{layout}]", C, want, 1e-4 if cdt == torch.float32 else TOL[cdt])
+
+
+def test_gemm_fast_epilogues(ops):
+    from vit_torch_amd._lib import (EPI_BIAS_GELU, EPI_DGELU, EPI_PATCH_POS, EPI_RESIDUAL, GEMM_FAST)
+    M, N, K = 512, 256, 192
+    bt = torch.bfloat16
+    a, b = bf16_round(gen((M, K), 3)), bf16_round(gen((N, K), 4, 0.2))
+    bias = gen((N,), 5)
+    A, B, Bt, bias_d = dev(a, bt), dev(b, bt), dev(b.t().contiguous(), bt), dev(bias)
+    acc = a @ b.t()
+    tol = TOL[bt]
+    C = torch.empty((M, N), device="cuda", dtype=bt)
+    ops.gemm(A, B, C, bias=bias_d, alpha=0.5, impl=GEMM_FAST)
+    assert_close("store", C, 0.5 * acc + bias, tol)
+    C32 = dev(gen((M, N), 6))
+    ops.gemm(A, B, C32, accumulate=True, impl=GEMM_FAST)
+    assert_close("accumulate", C32, gen((M, N), 6) + acc, 1e-4)
+    H = torch.empty((M, N), device="cuda", dtype=bt)
+    P = torch.empty((M, N), device="cuda", dtype=bt)
+    ops.gemm(A, B, H, epilogue=EPI_BIAS_GELU, bias=bias_d, C2=P, impl=GEMM_FAST)
+    assert_close("pre", P, acc + bias, tol)
+    assert_close("gelu", H, F.gelu(bf16_round(acc + bias)), tol)
+    for rdt in (torch.float32, bt):
+        r = gen((M, N), 7)
+        if rdt == bt:
+            r = bf16_round(r)
+        gam = gen((N,), 8)
+        X = torch.empty((M, N), device="cuda", dtype=rdt)
+        ops.gemm(A, B, X, epilogue=EPI_RESIDUAL, bias=bias_d, R=dev(r, rdt), gamma=dev(gam), impl=GEMM_FAST)
+        assert_close(f"residual[{rdt}]", X, r + gam * (acc + bias), TOL[rdt] if rdt == bt else 1e-4)
+        ops.gemm(A, B, X, epilogue=EPI_RESIDUAL, R=dev(r, rdt), impl=GEMM_FAST)
+        assert_close(f"residual-plain[{rdt}]", X, r + acc, TOL[rdt] if rdt == bt else 1e-4)
+    aux = bf16_round(gen((M, N), 9))
+    Dg = torch.empty((M, N), device="cuda", dtype=bt)
+    ops.gemm(A, Bt, Dg, b_kmajor=False, epilogue=EPI_DGELU, aux=dev(aux, bt), impl=GEMM_FAST)
+    assert_close("dgelu", Dg, acc * gelu_grad(aux), tol)
+    n_tok = 64
+    pos, cls = gen((n_tok, N), 10), gen((N,), 11)
+    t = torch.arange(M) % n_tok
+    want = acc + bias + pos[t]
+    want[t == 0] = cls + pos[0]
+    for rdt in (torch.float32, bt):
+        X = torch.empty((M, N), device="cuda", dtype=rdt)
+        ops.gemm(A, B, X, epilogue=EPI_PATCH_POS, bias=bias_d, pos=dev(pos), n_tok=n_tok, cls=dev(cls), impl=GEMM_FAST)
+        assert_close(f"patch_pos[{rdt}]", X, want, TOL[rdt] if rdt == bt else 1e-4)
+
+
+def test_gemm_fast_matches_generic_bitwise_on_integers(ops):
+    """Exact check of the fragment/tile index maps: small-integer operands make every
+    product and partial sum exact in fp32, so fast and generic must agree bit for bit
+    (asymmetric data, guide §3 'A=I-check with ASYMMETRIC B')."""
+    from vit_torch_amd._lib import GEMM_FAST, GEMM_GENERIC
+    M, N, K = 512, 512, 256
+    g = torch.Generator("cpu").manual_seed(5)
+    a = torch.randint(-4, 5, (M, K), generator=g).float()
+    b = torch.randint(-4, 5, (N, K), generator=g).float()
+    want = a @ b.t()
+    for akm, bkm in [(True, True), (True, False), (False, False)]:
+        A = dev(a if akm else a.t().contiguous(), torch.bfloat16)
+        B = dev(b if bkm else b.t().contiguous(), torch.bfloat16)
+        Cf = torch.empty((M, N), device="cuda")
+        Cg = torch.empty((M, N), device="cuda")
+        ops.gemm(A, B, Cf, a_kmajor=akm, b_kmajor=bkm, impl=GEMM_FAST)
+        ops.gemm(A, B, Cg, a_kmajor=akm, b_kmajor=bkm, impl=GEMM_GENERIC)
+        assert torch.equal(Cf.cpu(), want), f"fast kernel wrong for layout a_km={akm} b_km={bkm}"
+        assert torch.equal(Cg.cpu(), want)

@@ -1,4 +1,261 @@
-// placeholder until the LDS-DMA kernel lands (next commit)
+// Aligned-shape bf16 GEMM for gfx950: 256x256x64 tiles, 8 waves (2 x 4), each
+// wave a 128x64 output block as 8x4 v_mfma_f32_16x16x32_bf16 accumulators,
+// operands staged HBM -> LDS with global_load_lds_dwordx4 (LDS-DMA, no VGPR
+// round trip), double-buffered (2 x 64 KiB of the CU's 160 KiB LDS).
+//
+// Two LDS images, so that all three products of a Linear layer run without a
+// transposed copy of anything in HBM:
+//   * k-major operand  X[row][k]  (forward x and W, dgrad dy): "row image",
+//     1-KiB subtiles of 16 rows x 32 k, XOR-swizzled (byte bit5 ^= bit9) so
+//     the ds_read_b128 fragment reads are bank-conflict free;
+//   * k-minor operand  X[k][col]  (dgrad W, wgrad dy and x): "k-row image",
+//     512-B k-rows whose 32-B column chunks are XOR-permuted by
+//     key(k) = (k&3) | ((k>>3)&1)<<2, read with ds_read_b64_tr_b16 (hardware
+//     transpose) — conflict-free for the two 16-lane groups of a half-wave.
+// LDS-DMA writes lane-linearly, so both swizzles are applied to the per-lane
+// SOURCE address and again on the read (guide §5.4 rule 21).
+//
+// The MFMA is issued with the operands swapped (D^T = B^T-frag x A-frag) so a
+// lane ends up with 4 CONSECUTIVE output columns of one row: epilogue loads
+// (bias, residual, pre-activation) and stores are 8/16-byte vectors.
+//
+// Block -> tile map is XCD-aware (8 XCDs, private L2s): each XCD walks a
+// contiguous run of tiles, n fastest, so the A panel of a row of tiles and the
+// whole weight matrix stay in that XCD's L2.
 #include "epilogue.h"
-bool gemm_fast_supported(const GemmArgs&, int) { return false; }
-int gemm_fast_launch(const GemmArgs&, hipStream_t) { return vitmi_fail(VITMI_E_SHAPE, "gemm_fast: not built"); }
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int TILE_BYTES = 256 * 64 * 2;       // one operand tile: 32 KiB
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + B
+constexpr int NTHREADS = 512;
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// ---- staging: each wave issues 4 LDS-DMA instructions (1 KiB each) per tile
+template <bool KM>
+__device__ __forceinline__ void stage_tile(char* tile, const bf16* __restrict__ X, int64_t ld,
+                                           int64_t r0, int64_t k0, int wave, int lane) {
+  if constexpr (KM) {
+    const int pb = 16 * lane;
+    const int lb = pb ^ (((pb >> 9) & 1) << 5);
+    const int row = lb >> 6, ch = (lb & 63) >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int st = wave * 4 + i;          // subtile: 16 rows x 32 k
+      const int sr = st >> 1, kh = st & 1;
+      const bf16* src = X + (r0 + sr * 16 + row) * ld + k0 + kh * 32 + ch * 8;
+      glds16(src, tile + st * 1024);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = wave * 4 + i;           // pair of k-rows
+      const int row = 2 * j + (lane >> 5);
+      const int pc16 = lane & 31;
+      const int key = (row & 3) | (((row >> 3) & 1) << 2);
+      const int c32 = (pc16 >> 1) ^ key;
+      const bf16* src = X + (k0 + row) * ld + r0 + c32 * 16 + (pc16 & 1) * 8;
+      glds16(src, tile + j * 1024);
+    }
+  }
+}
+
+// ---- fragment reads: 16 rows (or cols) x 32 k of block rb, k-half kh
+template <bool KM>
+__device__ __forceinline__ bf16x8 load_frag(const char* tile, int rb, int kh, int lane) {
+  if constexpr (KM) {
+    int pb = (lane & 15) * 64 + (lane >> 4) * 16;
+    pb ^= ((pb >> 9) & 1) << 5;
+    return *reinterpret_cast<const bf16x8*>(tile + (rb * 2 + kh) * 1024 + pb);
+  } else {
+    const int g = lane >> 4, i = lane & 15;
+    const int row = 32 * kh + 8 * g + (i >> 2);
+    const int key = (row & 3) | (((row >> 3) & 1) << 2);
+    const char* p = tile + row * 512 + ((rb ^ key) * 32) + 8 * (i & 3);
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, p));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, p + 4 * 512));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+  }
+}
+
+// ---- vector epilogue: 4 consecutive columns n..n+3 of row m
+template <int MODE, typename TC>
+__device__ __forceinline__ void epi_store4(const EpiArgs& e, int64_t m, int64_t n, f32x4 acc) {
+  f32x4 v;
+  f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+  if (e.bias) b4 = *reinterpret_cast<const f32x4*>(e.bias + n);
+  TC* C = reinterpret_cast<TC*>(e.C);
+  if constexpr (MODE == VITMI_EPI_STORE) {
+    v = acc * e.alpha + b4;
+    if constexpr (sizeof(TC) == 4) {
+      if (e.accumulate) v += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(e.C) + m * e.ldc + n);
+    }
+  } else if constexpr (MODE == VITMI_EPI_BIAS_GELU) {
+    f32x4 pre = acc + b4;
+    if constexpr (sizeof(TC) == 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pre[i] = (float)(bf16)pre[i];
+    }
+    if (e.C2) store4<TC>(reinterpret_cast<TC*>(e.C2) + m * e.ldc2 + n, pre);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = gelu_erf(pre[i]);
+  } else if constexpr (MODE == VITMI_EPI_RESIDUAL) {
+    v = acc + b4;
+    if (e.gamma) v *= *reinterpret_cast<const f32x4*>(e.gamma + n);
+    v += load4<TC>(reinterpret_cast<const TC*>(e.R) + m * e.ldr + n);
+  } else if constexpr (MODE == VITMI_EPI_DGELU) {
+    const f32x4 a = load4<bf16>(reinterpret_cast<const bf16*>(e.AUX) + m * e.ldaux + n);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = acc[i] * dgelu_erf(a[i]);
+  } else {  // PATCH_POS
+    const int64_t t = m % e.n_tok;
+    if (t == 0 && e.cls)
+      v = *reinterpret_cast<const f32x4*>(e.cls + n) + *reinterpret_cast<const f32x4*>(e.pos + n);
+    else
+      v = acc + b4 + *reinterpret_cast<const f32x4*>(e.pos + t * e.ldpos + n);
+  }
+  store4<TC>(C + m * e.ldc + n, v);
+}
+
+template <bool A_KM, bool B_KM, int MODE, typename TC>
+__global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int tiles_n, int nwg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (A tile | B tile)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  // XCD-aware, bijective remap (guide §5: blocks b and b+8 share an XCD)
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int64_t m0 = (int64_t)(wg / tiles_n) * BM;
+  const int64_t n0 = (int64_t)(wg % tiles_n) * BN;
+
+  const bf16* A = reinterpret_cast<const bf16*>(g.A);
+  const bf16* B = reinterpret_cast<const bf16*>(g.B);
+
+  f32x4 acc[4][8];   // [ni][mi]: D^T blocks, lane holds row m = l&15, cols n = 4*(l>>4)+r
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) { acc[ni][mi][0] = 0.f; acc[ni][mi][1] = 0.f; acc[ni][mi][2] = 0.f; acc[ni][mi][3] = 0.f; }
+
+  const int nt = (int)(g.K / BK);
+  stage_tile<A_KM>(smem, A, g.lda, m0, 0, wave, lane);
+  stage_tile<B_KM>(smem + TILE_BYTES, B, g.ldb, n0, 0, wave, lane);
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    char* cur = smem + (t & 1) * STAGE_BYTES;
+    if (t + 1 < nt) {
+      char* nxt = smem + ((t + 1) & 1) * STAGE_BYTES;
+      stage_tile<A_KM>(nxt, A, g.lda, m0, (int64_t)(t + 1) * BK, wave, lane);
+      stage_tile<B_KM>(nxt + TILE_BYTES, B, g.ldb, n0, (int64_t)(t + 1) * BK, wave, lane);
+    }
+    const char* At = cur;
+    const char* Bt = cur + TILE_BYTES;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      bf16x8 bf[4], af[8];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) bf[ni] = load_frag<B_KM>(Bt, wn * 4 + ni, kh, lane);
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) af[mi] = load_frag<A_KM>(At, wm * 8 + mi, kh, lane);
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+    }
+    __syncthreads();   // next stage landed (vmcnt(0)) and everyone is done reading `cur`
+  }
+
+  const int lr = lane & 15, lg = lane >> 4;
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    const int64_t m = m0 + wm * 128 + mi * 16 + lr;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int64_t n = n0 + wn * 64 + ni * 16 + lg * 4;
+      epi_store4<MODE, TC>(g.e, m, n, acc[ni][mi]);
+    }
+  }
+}
+
+template <bool A_KM, bool B_KM, int MODE, typename TC>
+int launch(const GemmArgs& g, hipStream_t stream) {
+  const int tiles_m = (int)(g.M / BM), tiles_n = (int)(g.N / BN);
+  const int nwg = tiles_m * tiles_n;
+  auto kern = gemm_fast_kernel<A_KM, B_KM, MODE, TC>;
+  static bool attr_set = false;   // per instantiation
+  if (!attr_set) {
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    if (err != hipSuccess) return vitmi_fail((int)err, "gemm_fast: cannot raise dynamic LDS to %d: %s", 2 * STAGE_BYTES, hipGetErrorString(err));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(NTHREADS), 2 * STAGE_BYTES, stream, g, tiles_n, nwg);
+  return vitmi_check_launch("gemm_fast_kernel");
+}
+
+enum { OUT_BF16 = 0, OUT_F32 = 1 };
+
+}  // namespace
+
+// which (layout, epilogue, output dtype) combinations are instantiated
+static bool combo_built(const GemmArgs& g) {
+  const EpiArgs& e = g.e;
+  const bool nt = g.a_km && g.b_km, nn = g.a_km && !g.b_km, tn = !g.a_km && !g.b_km;
+  switch (e.mode) {
+    case VITMI_EPI_STORE: return (nt || nn || tn);
+    case VITMI_EPI_BIAS_GELU: return nt && e.c_bf16;
+    case VITMI_EPI_RESIDUAL: return nt;
+    case VITMI_EPI_DGELU: return nn && e.c_bf16;
+    case VITMI_EPI_PATCH_POS: return nt;
+  }
+  return false;
+}
+
+bool gemm_fast_supported(const GemmArgs& g, int in_bf16) {
+  if (!in_bf16) return false;
+  if (g.M % BM || g.N % BN || g.K % BK) return false;
+  if (g.M / BM * (g.N / BN) > (1 << 30)) return false;
+  if (!combo_built(g)) return false;
+  const EpiArgs& e = g.e;
+  if (g.lda % 8 || g.ldb % 8 || !is_aligned(g.A, 16) || !is_aligned(g.B, 16)) return false;
+  const size_t cb = e.c_bf16 ? 8 : 16;
+  if (e.ldc % 4 || !is_aligned(e.C, cb)) return false;
+  if (e.C2 && (e.ldc2 % 4 || !is_aligned(e.C2, cb))) return false;
+  if (e.bias && !is_aligned(e.bias, 16)) return false;
+  if (e.gamma && !is_aligned(e.gamma, 16)) return false;
+  if (e.mode == VITMI_EPI_RESIDUAL && (e.ldr % 4 || !is_aligned(e.R, cb))) return false;
+  if (e.mode == VITMI_EPI_DGELU && (e.ldaux % 4 || !is_aligned(e.AUX, 8))) return false;
+  if (e.mode == VITMI_EPI_PATCH_POS && (!is_aligned(e.pos, 16) || (e.cls && !is_aligned(e.cls, 16)))) return false;
+  if (e.mode == VITMI_EPI_STORE && e.accumulate && e.c_bf16) return false;
+  return true;
+}
+
+int gemm_fast_launch(const GemmArgs& g, hipStream_t s) {
+  const EpiArgs& e = g.e;
+  const bool nt = g.a_km && g.b_km, nn = g.a_km && !g.b_km;
+#define GO(AKM, BKM, MODE) (e.c_bf16 ? launch<AKM, BKM, MODE, bf16>(g, s) : launch<AKM, BKM, MODE, float>(g, s))
+  switch (e.mode) {
+    case VITMI_EPI_STORE:
+      if (nt) return GO(true, true, VITMI_EPI_STORE);
+      if (nn) return GO(true, false, VITMI_EPI_STORE);
+      return GO(false, false, VITMI_EPI_STORE);
+    case VITMI_EPI_BIAS_GELU: return launch<true, true, VITMI_EPI_BIAS_GELU, bf16>(g, s);
+    case VITMI_EPI_RESIDUAL: return GO(true, true, VITMI_EPI_RESIDUAL);
+    case VITMI_EPI_DGELU: return launch<true, false, VITMI_EPI_DGELU, bf16>(g, s);
+    case VITMI_EPI_PATCH_POS: return GO(true, true, VITMI_EPI_PATCH_POS);
+  }
+#undef GO
+  return vitmi_fail(VITMI_E_SHAPE, "gemm_fast: combination not built");
+}

@@ -1,0 +1,70 @@
+"""Data-parallel gradient exchange: one process per GPU, RCCL over xGMI.
+
+The reference is single-process; this is the build's
+multi-GPU path.  Gradients live in ONE flat fp32 buffer laid out in
+named_parameters order, and the backward pass finishes whole sections of it
+(head+norm, then blocks depth-1 .. 0, then the embeddings), so a bucket is a
+contiguous slice: it is all-reduced IN PLACE (no packing copy) with
+`async_op=True` the moment its section is complete.  ProcessGroupNCCL runs the
+collective on its own HIP stream, ordered after the kernels already queued on
+the compute stream, so the exchange of block i overlaps the backward of blocks
+i-1.. .  `finish()` makes the compute stream wait for every bucket; the SUM is
+turned into the mean by the optimizer's `grad_scale = 1/world` (one fewer pass
+over the gradients).  xGMI is point-to-point, so buckets are kept large
+(one transformer block = 28 MB fp32 for ViT-B) rather than many small ones.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    def __init__(self, pack, group=None, min_bucket_elems: int = 4 << 20):
+        self.pack = pack
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.min_bucket = int(min_bucket_elems)
+        self._pending_lo: Optional[int] = None
+        self._pending_hi: Optional[int] = None
+        self._works: List = []
+        self.launched: List[tuple] = []      # (lo, hi) of every bucket, for tests
+
+    # called by the engine when the gradients of `params` are final
+    def section_ready(self, params) -> None:
+        if self.world == 1 or not params:
+            return
+        lo, hi = self.pack.span(params)
+        if self._pending_lo is None:
+            self._pending_lo, self._pending_hi = lo, hi
+        else:
+            if hi != self._pending_lo and lo != self._pending_hi:
+                self._flush()                 # not adjacent: send what we have
+                self._pending_lo, self._pending_hi = lo, hi
+            else:
+                self._pending_lo = min(lo, self._pending_lo)
+                self._pending_hi = max(hi, self._pending_hi)
+        if self._pending_hi - self._pending_lo >= self.min_bucket:
+            self._flush()
+
+    def _flush(self) -> None:
+        if self._pending_lo is None:
+            return
+        lo, hi = self._pending_lo, self._pending_hi
+        self._pending_lo = self._pending_hi = None
+        buf = self.pack.grad[lo:hi]
+        self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.launched.append((lo, hi))
+
+    def finish(self) -> None:
+        """Order the current stream after every outstanding bucket."""
+        self._flush()
+        for w in self._works:
+            w.wait()
+        self._works.clear()
+
+    def broadcast_parameters(self, src: int = 0) -> None:
+        if self.world > 1:
+            dist.broadcast(self.pack.flat, src=src, group=self.group)

@@ -186,6 +186,8 @@ class VitEngine:
         self.pack = ParamPack(named, dev, shadow=self.T == torch.bfloat16)
         self.saved = None
         self.gemm_impl = GEMM_AUTO
+        self.reducer = None          # ddp.GradReducer: told when a section's grads are final
+        self.profile = None          # list of (name, flops, start_event, end_event) when profiling
 
     def is_current(self) -> bool:
         m = self.model
@@ -196,8 +198,26 @@ class VitEngine:
     def _w(self, p):
         return self.pack.w(p)
 
-    def _gemm(self, *a, **k):
-        return ops.gemm(*a, impl=self.gemm_impl, **k)
+    def _gemm(self, A, B, C, **k):
+        if self.profile is None:
+            return ops.gemm(A, B, C, impl=self.gemm_impl, **k)
+        akm, bkm = k.get("a_kmajor", True), k.get("b_kmajor", True)
+        Kdim = A.shape[1] if akm else A.shape[0]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.gemm(A, B, C, impl=self.gemm_impl, **k)
+        e1.record()
+        name = "gemm_" + ("n" if akm else "t") + ("t" if bkm else "n")
+        self.profile.append((name, (C.shape[0], C.shape[1], Kdim), 2.0 * C.shape[0] * C.shape[1] * Kdim, e0, e1))
+        return C
+
+    def _ready(self, *mods_or_params):
+        if self.reducer is None:
+            return
+        ps = []
+        for o in mods_or_params:
+            ps.extend(o.parameters() if isinstance(o, nn.Module) else [o])
+        self.reducer.section_ready(ps)
 
     def _pos_for(self, gh, gw):
         """pos_embed at the input's patch grid: as stored, or the bicubic resize
@@ -347,6 +367,7 @@ class VitEngine:
         ops.layernorm_bwd(dfeat, s["Xf"], s["meanf"], s["rstdf"], pk.f32(m.norm.weight), None, G, None,
                           pk.g(m.norm.weight), pk.g(m.norm.bias), M=B, D=D,
                           dy_stride=D, x_stride=N * D, g_stride=N * D)
+        self._ready(m.norm, *([m.head] if self.head else []))
         if T == R:
             Gb = G                      # GEMM operand and residual gradient share one buffer
         else:
@@ -386,6 +407,7 @@ class VitEngine:
                 ops.colsum(dqkv, pk.g(a.qkv.bias))
             ops.layernorm_bwd(dln1, X, mean1, rstd1, pk.f32(blk.norm1.weight), G, G, gb_out,
                               pk.g(blk.norm1.weight), pk.g(blk.norm1.bias), M=M, D=D)
+            self._ready(blk)
 
         # ---- embeddings ----
         conv = m.patch_embed.proj
@@ -402,3 +424,6 @@ class VitEngine:
         self._gemm(Gb, s["patches"], pk.g(conv.weight).view(D, Kp), a_kmajor=False, b_kmajor=False)
         if conv.bias is not None:
             ops.colsum(dpos[D:].view(N - 1, D), pk.g(conv.bias))  # CLS rows carry no conv bias
+        self._ready(m.cls_token, m.pos_embed, m.patch_embed)
+        if self.reducer is not None:
+            self.reducer.finish()
