@@ -50,7 +50,13 @@ def cpu_baseline(arch, img, batch, steps):
     """Oracle timed on the host cores (test infrastructure used as the CPU baseline)."""
     import torch.nn.functional as F
     from oracle import vit_ref
-    cores = os.cpu_count() or 1
+    # the box's CPU share, not the host's core count: oversubscribing 256 "cores" of a
+    # 16-CPU cgroup made the first run 30x slower
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
     torch.set_num_threads(cores)
     model = vit_ref.build(arch, classifier=10, img_size=img)
     vit_ref.seeded_init_(model, 1)

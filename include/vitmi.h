@@ -87,9 +87,14 @@ typedef struct vitmi_gemm_desc {
   float alpha;                 /* scale on acc for EPI_STORE (0 -> 1)        */
   int32_t accumulate;          /* EPI_STORE fp32 only: C += ...              */
   int32_t impl;                /* VITMI_GEMM_*                               */
+  void* workspace;             /* optional scratch, >= vitmi_gemm_workspace(d) */
+  size_t workspace_bytes;      /* (without it split-K is not used: slower)    */
 } vitmi_gemm_desc;
 
 int vitmi_gemm(const vitmi_gemm_desc* d, void* stream);
+/* bytes of scratch that let the fast kernel split the contraction over more
+ * workgroups (weight gradients: few output tiles, K = all tokens); 0 if none */
+size_t vitmi_gemm_workspace(const vitmi_gemm_desc* d);
 /* 1 if the aligned-shape MFMA/LDS-DMA kernel would be used for d, 0 if the
  * generic strided kernel would (tests assert the hot shapes take the fast one) */
 int vitmi_gemm_uses_fast(const vitmi_gemm_desc* d);

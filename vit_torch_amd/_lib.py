@@ -32,6 +32,7 @@ class GemmDesc(C.Structure):
         ("AUX", c_vp), ("ldaux", c_i64),
         ("pos", c_vp), ("n_tok", c_i64), ("cls", c_vp),
         ("alpha", c_f32), ("accumulate", c_i32), ("impl", c_i32),
+        ("workspace", c_vp), ("workspace_bytes", c_sz),
     ]
 
 
@@ -41,6 +42,7 @@ SIGNATURES = {
     "vitmi_last_error_string": (C.c_char_p, []),
     "vitmi_gemm": (C.c_int, [C.POINTER(GemmDesc), c_vp]),
     "vitmi_gemm_uses_fast": (C.c_int, [C.POINTER(GemmDesc)]),
+    "vitmi_gemm_workspace": (c_sz, [C.POINTER(GemmDesc)]),
     "vitmi_layernorm_fwd": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, c_vp, c_vp, C.c_int, c_i64,
                                       c_vp, c_vp, c_i64, c_i64, c_f32, c_vp]),
     "vitmi_layernorm_bwd_workspace": (c_sz, [c_i64, c_i64]),

@@ -19,6 +19,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 void vitmi_set_error(const std::string& s);
 int vitmi_fail(int code, const char* fmt, ...);
 int vitmi_check_launch(const char* what);
+// out[c] = sum_{r<S} part[r*ld + c], c < N (elementwise.hip)
+int vitmi_reduce_rows(const float* part, int S, int64_t N, int64_t ld, float* out, hipStream_t stream);
 
 #define VITMI_REQUIRE(cond, code, ...)                  \
   do {                                                  \

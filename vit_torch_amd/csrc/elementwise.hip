@@ -93,13 +93,25 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
   }
 }
 
-__global__ void colsum_final_kernel(const float* __restrict__ part, int S, int64_t N,
-                                    float* __restrict__ out) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= N) return;
+// out[c] = sum_{r<S} part[r*ld + c]: 64 columns per block, the S rows split over
+// 16 waves (coalesced 256-B row segments), fixed summation order (deterministic)
+__global__ __launch_bounds__(1024) void reduce_rows_kernel(const float* __restrict__ part, int S,
+                                                           int64_t N, int64_t ld,
+                                                           float* __restrict__ out) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + lane;
   float s = 0.f;
-  for (int r = 0; r < S; ++r) s += part[(int64_t)r * N + c];
-  out[c] = s;
+  if (c < N)
+    for (int r = w; r < S; r += 16) s += part[(int64_t)r * ld + c];
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && c < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][lane];
+    out[c] = t;
+  }
 }
 
 inline int colsum_splits(int64_t M) {
@@ -199,6 +211,11 @@ __global__ void sgd_momentum_kernel(float* __restrict__ p, const float* __restri
 
 }  // namespace
 
+int vitmi_reduce_rows(const float* part, int S, int64_t N, int64_t ld, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((N + 63) / 64)), dim3(1024), 0, stream, part, S, N, ld, out);
+  return vitmi_check_launch("reduce_rows_kernel");
+}
+
 extern "C" int vitmi_cast(const void* src, int sd, void* dst, int dd, int64_t n, void* stream_) {
   VITMI_REQUIRE(src && dst && n > 0, VITMI_E_BADARG, "cast: null pointer or n <= 0");
   VITMI_REQUIRE(is_aligned(src, 4 * dtype_size(sd)) && is_aligned(dst, 4 * dtype_size(dd)), VITMI_E_ALIGN, "cast: pointers must be 4-element aligned");
@@ -255,8 +272,7 @@ extern "C" int vitmi_colsum(const void* x, int dtype, int64_t M, int64_t N, int6
   } else return vitmi_fail(VITMI_E_DTYPE, "colsum: bad dtype");
   int rc = vitmi_check_launch("colsum_partial_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, part, S, N, out);
-  return vitmi_check_launch("colsum_final_kernel");
+  return vitmi_reduce_rows(part, S, N, N, out, stream);
 }
 
 extern "C" int vitmi_softmax_xent(const float* logits, const int64_t* labels, float* loss,

@@ -20,6 +20,7 @@ struct GemmArgs {
   int64_t M, N, K;
   const void* A; int64_t lda; int a_km;
   const void* B; int64_t ldb; int b_km;
+  void* ws; size_t ws_bytes;      // optional scratch (split-K partial tiles)
   EpiArgs e;
 };
 

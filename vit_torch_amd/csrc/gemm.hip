@@ -9,6 +9,7 @@
 
 bool gemm_fast_supported(const GemmArgs& g, int in_bf16);
 int gemm_fast_launch(const GemmArgs& g, hipStream_t stream);
+size_t gemm_fast_workspace(const GemmArgs& g);
 
 namespace {
 
@@ -102,6 +103,8 @@ static int build_args(const vitmi_gemm_desc* d, GemmArgs* out) {
   g.M = d->M; g.N = d->N; g.K = d->K;
   g.A = d->A; g.lda = d->lda; g.a_km = d->a_kmajor ? 1 : 0;
   g.B = d->B; g.ldb = d->ldb; g.b_km = d->b_kmajor ? 1 : 0;
+  g.ws = d->workspace; g.ws_bytes = d->workspace_bytes;
+  if (g.ws && !is_aligned(g.ws, 16)) { g.ws = nullptr; g.ws_bytes = 0; }
   EpiArgs& e = g.e;
   e.mode = d->epilogue;
   e.C = d->C; e.ldc = d->ldc; e.c_bf16 = d->c_dtype == VITMI_BF16;
@@ -140,6 +143,13 @@ extern "C" int vitmi_gemm_uses_fast(const vitmi_gemm_desc* d) {
   if (build_args(d, &g) != 0) return 0;
   if (d->impl == VITMI_GEMM_GENERIC) return 0;
   return gemm_fast_supported(g, d->in_dtype == VITMI_BF16) ? 1 : 0;
+}
+
+extern "C" size_t vitmi_gemm_workspace(const vitmi_gemm_desc* d) {
+  GemmArgs g;
+  if (build_args(d, &g) != 0 || d->impl == VITMI_GEMM_GENERIC) return 0;
+  if (!gemm_fast_supported(g, d->in_dtype == VITMI_BF16)) return 0;
+  return gemm_fast_workspace(g);
 }
 
 extern "C" int vitmi_gemm(const vitmi_gemm_desc* d, void* stream_) {

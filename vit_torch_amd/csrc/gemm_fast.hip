@@ -125,8 +125,14 @@ __device__ __forceinline__ void epi_store4(const EpiArgs& e, int64_t m, int64_t 
   store4<TC>(C + m * e.ldc + n, v);
 }
 
-template <bool A_KM, bool B_KM, int MODE, typename TC>
-__global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int tiles_n, int nwg) {
+// SPLITK: the grid is (tiles x splits); block (tile, s) contracts k-steps
+// [s*ksps, min((s+1)*ksps, nt)) and stores its raw fp32 partial tile into slab s
+// of `ws` ([splits][M][N]); splitk_reduce_kernel sums the slabs in a fixed order
+// (deterministic) and applies the epilogue.  Used for the weight gradients,
+// whose output is only 9-48 tiles while the contraction runs over all M tokens.
+template <bool A_KM, bool B_KM, int MODE, typename TC, bool SPLITK = false>
+__global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int tiles_n, int nwg,
+                                                             int ntiles, int ksps, float* ws) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (A tile | B tile)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -136,8 +142,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
   const int bid = blockIdx.x;
   const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
   const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  const int64_t m0 = (int64_t)(wg / tiles_n) * BM;
-  const int64_t n0 = (int64_t)(wg % tiles_n) * BN;
+  // consecutive wg share the split (k range) and walk the tiles: operand panels stay in L2
+  const int split = SPLITK ? wg / ntiles : 0;
+  const int tile = SPLITK ? wg % ntiles : wg;
+  const int64_t m0 = (int64_t)(tile / tiles_n) * BM;
+  const int64_t n0 = (int64_t)(tile % tiles_n) * BN;
 
   const bf16* A = reinterpret_cast<const bf16*>(g.A);
   const bf16* B = reinterpret_cast<const bf16*>(g.B);
@@ -148,17 +157,19 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) { acc[ni][mi][0] = 0.f; acc[ni][mi][1] = 0.f; acc[ni][mi][2] = 0.f; acc[ni][mi][3] = 0.f; }
 
-  const int nt = (int)(g.K / BK);
-  stage_tile<A_KM>(smem, A, g.lda, m0, 0, wave, lane);
-  stage_tile<B_KM>(smem + TILE_BYTES, B, g.ldb, n0, 0, wave, lane);
+  const int nt_all = (int)(g.K / BK);
+  const int kt0 = SPLITK ? split * ksps : 0;
+  const int nt = SPLITK ? min(ksps, nt_all - kt0) : nt_all;
+  stage_tile<A_KM>(smem, A, g.lda, m0, (int64_t)kt0 * BK, wave, lane);
+  stage_tile<B_KM>(smem + TILE_BYTES, B, g.ldb, n0, (int64_t)kt0 * BK, wave, lane);
   __syncthreads();
 
   for (int t = 0; t < nt; ++t) {
     char* cur = smem + (t & 1) * STAGE_BYTES;
     if (t + 1 < nt) {
       char* nxt = smem + ((t + 1) & 1) * STAGE_BYTES;
-      stage_tile<A_KM>(nxt, A, g.lda, m0, (int64_t)(t + 1) * BK, wave, lane);
-      stage_tile<B_KM>(nxt + TILE_BYTES, B, g.ldb, n0, (int64_t)(t + 1) * BK, wave, lane);
+      stage_tile<A_KM>(nxt, A, g.lda, m0, (int64_t)(kt0 + t + 1) * BK, wave, lane);
+      stage_tile<B_KM>(nxt + TILE_BYTES, B, g.ldb, n0, (int64_t)(kt0 + t + 1) * BK, wave, lane);
     }
     const char* At = cur;
     const char* Bt = cur + TILE_BYTES;
@@ -185,23 +196,75 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       const int64_t n = n0 + wn * 64 + ni * 16 + lg * 4;
-      epi_store4<MODE, TC>(g.e, m, n, acc[ni][mi]);
+      if constexpr (SPLITK)
+        *reinterpret_cast<f32x4*>(ws + ((int64_t)split * g.M + m) * g.N + n) = acc[ni][mi];
+      else
+        epi_store4<MODE, TC>(g.e, m, n, acc[ni][mi]);
     }
   }
+}
+
+// C = epilogue(sum_s ws[s]) for EPI_STORE, fp32 C; one thread = 4 columns
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, EpiArgs e, int64_t M,
+                                     int64_t N) {
+  const int64_t n4 = N / 4;
+  const int64_t total = M * n4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / n4, n = (i % n4) * 4;
+    f32x4 acc = *reinterpret_cast<const f32x4*>(ws + m * N + n);
+    for (int s = 1; s < splits; ++s) acc += *reinterpret_cast<const f32x4*>(ws + ((int64_t)s * M + m) * N + n);
+    epi_store4<VITMI_EPI_STORE, float>(e, m, n, acc);
+  }
+}
+
+// split-K plan for a problem with `tiles` output tiles and `nt` k-steps
+inline void splitk_plan(int tiles, int nt, int* splits, int* ksps) {
+  int s = 1;
+  if (tiles <= 128 && nt >= 16) {
+    s = 256 / tiles;
+    if (s > nt / 8) s = nt / 8;
+    if (s < 1) s = 1;
+  }
+  const int k = (nt + s - 1) / s;
+  *ksps = k;
+  *splits = (nt + k - 1) / k;
 }
 
 template <bool A_KM, bool B_KM, int MODE, typename TC>
 int launch(const GemmArgs& g, hipStream_t stream) {
   const int tiles_m = (int)(g.M / BM), tiles_n = (int)(g.N / BN);
   const int nwg = tiles_m * tiles_n;
-  auto kern = gemm_fast_kernel<A_KM, B_KM, MODE, TC>;
+  if constexpr (MODE == VITMI_EPI_STORE && sizeof(TC) == 4) {
+    int splits, ksps;
+    splitk_plan(nwg, (int)(g.K / BK), &splits, &ksps);
+    if (splits > 1 && g.ws && g.ws_bytes >= (size_t)splits * g.M * g.N * sizeof(float)) {
+      auto kern = gemm_fast_kernel<A_KM, B_KM, MODE, TC, true>;
+      static bool attr_set_sk = false;
+      if (!attr_set_sk) {
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+        if (err != hipSuccess) return vitmi_fail((int)err, "gemm_fast: cannot raise dynamic LDS: %s", hipGetErrorString(err));
+        attr_set_sk = true;
+      }
+      float* ws = reinterpret_cast<float*>(g.ws);
+      hipLaunchKernelGGL(kern, dim3(nwg * splits), dim3(NTHREADS), 2 * STAGE_BYTES, stream, g, tiles_n, nwg * splits, nwg, ksps, ws);
+      int rc = vitmi_check_launch("gemm_fast_kernel(split-K)");
+      if (rc) return rc;
+      const int64_t work = g.M * g.N / 4;
+      int64_t blocks = (work + 255) / 256;
+      if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, ws, splits, g.e, g.M, g.N);
+      return vitmi_check_launch("splitk_reduce_kernel");
+    }
+  }
+  auto kern = gemm_fast_kernel<A_KM, B_KM, MODE, TC, false>;
   static bool attr_set = false;   // per instantiation
   if (!attr_set) {
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     if (err != hipSuccess) return vitmi_fail((int)err, "gemm_fast: cannot raise dynamic LDS to %d: %s", 2 * STAGE_BYTES, hipGetErrorString(err));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(NTHREADS), 2 * STAGE_BYTES, stream, g, tiles_n, nwg);
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(NTHREADS), 2 * STAGE_BYTES, stream, g, tiles_n, nwg, nwg, 0, (float*)nullptr);
   return vitmi_check_launch("gemm_fast_kernel");
 }
 
@@ -240,6 +303,13 @@ bool gemm_fast_supported(const GemmArgs& g, int in_bf16) {
   if (e.mode == VITMI_EPI_PATCH_POS && (!is_aligned(e.pos, 16) || (e.cls && !is_aligned(e.cls, 16)))) return false;
   if (e.mode == VITMI_EPI_STORE && e.accumulate && e.c_bf16) return false;
   return true;
+}
+
+size_t gemm_fast_workspace(const GemmArgs& g) {
+  if (g.e.mode != VITMI_EPI_STORE || g.e.c_bf16) return 0;
+  int splits, ksps;
+  splitk_plan((int)(g.M / BM * (g.N / BN)), (int)(g.K / BK), &splits, &ksps);
+  return splits > 1 ? (size_t)splits * g.M * g.N * sizeof(float) : 0;
 }
 
 int gemm_fast_launch(const GemmArgs& g, hipStream_t s) {

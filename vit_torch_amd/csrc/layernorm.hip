@@ -143,15 +143,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
   }
 }
 
-__global__ void ln_bwd_reduce_kernel(const float* __restrict__ part, int nrows, int D,
-                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= 2 * D) return;
-  float s = 0.f;
-  for (int r = 0; r < nrows; ++r) s += part[(int64_t)r * 2 * D + c];
-  if (c < D) dgamma[c] = s; else dbeta[c - D] = s;
-}
-
 inline int ln_bwd_blocks(int64_t M) {
   int64_t b = (M + 3) / 4;
   return (int)(b < 512 ? b : 512);
@@ -229,7 +220,7 @@ extern "C" int vitmi_layernorm_bwd(const void* dy, int dy_dtype, int64_t dy_stri
 #undef LN_BWD
   rc = vitmi_check_launch("ln_bwd_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((2 * D + 255) / 256)), dim3(256), 0, stream,
-                     part, nblk, (int)D, dgamma, dbeta);
-  return vitmi_check_launch("ln_bwd_reduce_kernel");
+  rc = vitmi_reduce_rows(part, nblk, D, 2 * D, dgamma, stream);
+  if (rc) return rc;
+  return vitmi_reduce_rows(part + D, nblk, D, 2 * D, dbeta, stream);
 }

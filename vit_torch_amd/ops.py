@@ -92,7 +92,12 @@ def gemm(A, B, C_out, *, a_kmajor=True, b_kmajor=True, epilogue=EPI_STORE, bias=
     d.alpha = float(alpha)
     d.accumulate = int(accumulate)
     d.impl = impl
-    check(load().vitmi_gemm(C.byref(d), _stream()), "vitmi_gemm")
+    lib = load()
+    need = lib.vitmi_gemm_workspace(C.byref(d))
+    if need:
+        ws = workspace(need, A.device)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    check(lib.vitmi_gemm(C.byref(d), _stream()), "vitmi_gemm")
     return C_out
 
 
