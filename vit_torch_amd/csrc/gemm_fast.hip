@@ -86,44 +86,123 @@ __device__ __forceinline__ bf16x8 load_frag(const char* tile, int rb, int kh, in
   }
 }
 
-// ---- vector epilogue: 4 consecutive columns n..n+3 of row m
-template <int MODE, typename TC>
-__device__ __forceinline__ void epi_store4(const EpiArgs& e, int64_t m, int64_t n, f32x4 acc) {
-  f32x4 v;
-  f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-  if (e.bias) b4 = *reinterpret_cast<const f32x4*>(e.bias + n);
+// ---- fast GELU for the bf16 epilogues: erf by Abramowitz-Stegun 7.1.26
+// (|abs err| <= 1.5e-7, far below bf16 resolution); ONE exp serves both the erf
+// tail and the Gaussian pdf, so gelu' costs no second transcendental.  The fp32
+// parity mode (generic kernel) keeps erff.
+__device__ __forceinline__ void gelu_parts(float x, float* cdf, float* pdf) {
+  const float ax = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * ax);
+  const float ex = __expf(-ax * ax);                      // exp(-x^2/2)
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f +
+                     t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.f - poly * ex;
+  *cdf = 0.5f * (1.f + copysignf(erf_abs, x));
+  *pdf = 0.39894228040143267794f * ex;
+}
+
+// ---- W-wide row vectors (W = 8 for bf16 outputs = 16 B, W = 4 for fp32 = 16 B)
+template <typename T, int W>
+__device__ __forceinline__ void loadv(const T* p, float (&o)[W]) {
+  if constexpr (sizeof(T) == 2 && W == 8) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+  } else {
+#pragma unroll
+    for (int q = 0; q < W / 4; ++q) {
+      const f32x4 v = load4<T>(p + 4 * q);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[4 * q + i] = v[i];
+    }
+  }
+}
+template <typename T, int W>
+__device__ __forceinline__ void storev(T* p, const float (&v)[W]) {
+  if constexpr (sizeof(T) == 2 && W == 8) {
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (bf16)v[i];
+    *reinterpret_cast<bf16x8*>(p) = o;
+  } else {
+#pragma unroll
+    for (int q = 0; q < W / 4; ++q) {
+      const f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+      store4<T>(p + 4 * q, o);
+    }
+  }
+}
+
+// epilogue on W consecutive columns n.. of row m; v = raw accumulators in, stored out
+template <int MODE, typename TC, int W>
+__device__ __forceinline__ void epi_row(const EpiArgs& e, int64_t m, int64_t n, float (&v)[W]) {
+  float b[W];
+#pragma unroll
+  for (int i = 0; i < W; ++i) b[i] = 0.f;
+  if (e.bias) loadv<float, W>(e.bias + n, b);
   TC* C = reinterpret_cast<TC*>(e.C);
   if constexpr (MODE == VITMI_EPI_STORE) {
-    v = acc * e.alpha + b4;
+#pragma unroll
+    for (int i = 0; i < W; ++i) v[i] = v[i] * e.alpha + b[i];
     if constexpr (sizeof(TC) == 4) {
-      if (e.accumulate) v += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(e.C) + m * e.ldc + n);
+      if (e.accumulate) {
+        float c[W];
+        loadv<float, W>(reinterpret_cast<const float*>(e.C) + m * e.ldc + n, c);
+#pragma unroll
+        for (int i = 0; i < W; ++i) v[i] += c[i];
+      }
     }
   } else if constexpr (MODE == VITMI_EPI_BIAS_GELU) {
-    f32x4 pre = acc + b4;
-    if constexpr (sizeof(TC) == 2) {
+    float pre[W];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) pre[i] = (float)(bf16)pre[i];
+    for (int i = 0; i < W; ++i) {
+      pre[i] = v[i] + b[i];
+      if constexpr (sizeof(TC) == 2) pre[i] = (float)(bf16)pre[i];
+      float cdf, pdf;
+      gelu_parts(pre[i], &cdf, &pdf);
+      v[i] = pre[i] * cdf;
     }
-    if (e.C2) store4<TC>(reinterpret_cast<TC*>(e.C2) + m * e.ldc2 + n, pre);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = gelu_erf(pre[i]);
+    if (e.C2) storev<TC, W>(reinterpret_cast<TC*>(e.C2) + m * e.ldc2 + n, pre);
   } else if constexpr (MODE == VITMI_EPI_RESIDUAL) {
-    v = acc + b4;
-    if (e.gamma) v *= *reinterpret_cast<const f32x4*>(e.gamma + n);
-    v += load4<TC>(reinterpret_cast<const TC*>(e.R) + m * e.ldr + n);
-  } else if constexpr (MODE == VITMI_EPI_DGELU) {
-    const f32x4 a = load4<bf16>(reinterpret_cast<const bf16*>(e.AUX) + m * e.ldaux + n);
+    float r[W];
+    loadv<TC, W>(reinterpret_cast<const TC*>(e.R) + m * e.ldr + n, r);
+    if (e.gamma) {
+      float gm[W];
+      loadv<float, W>(e.gamma + n, gm);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = acc[i] * dgelu_erf(a[i]);
+      for (int i = 0; i < W; ++i) v[i] = r[i] + gm[i] * (v[i] + b[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < W; ++i) v[i] = r[i] + (v[i] + b[i]);
+    }
+  } else if constexpr (MODE == VITMI_EPI_DGELU) {
+    float a[W];
+    loadv<bf16, W>(reinterpret_cast<const bf16*>(e.AUX) + m * e.ldaux + n, a);
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+      float cdf, pdf;
+      gelu_parts(a[i], &cdf, &pdf);
+      v[i] *= cdf + a[i] * pdf;
+    }
   } else {  // PATCH_POS
     const int64_t t = m % e.n_tok;
-    if (t == 0 && e.cls)
-      v = *reinterpret_cast<const f32x4*>(e.cls + n) + *reinterpret_cast<const f32x4*>(e.pos + n);
-    else
-      v = acc + b4 + *reinterpret_cast<const f32x4*>(e.pos + t * e.ldpos + n);
+    float ps[W];
+    loadv<float, W>(e.pos + t * e.ldpos + n, ps);
+    if (t == 0 && e.cls) {
+      float c[W];
+      loadv<float, W>(e.cls + n, c);
+#pragma unroll
+      for (int i = 0; i < W; ++i) v[i] = c[i] + ps[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < W; ++i) v[i] = v[i] + b[i] + ps[i];
+    }
   }
-  store4<TC>(C + m * e.ldc + n, v);
+  storev<TC, W>(C + m * e.ldc + n, v);
 }
+
+constexpr int TRS = 68;                       // floats per row of the transpose strip (64 + pad)
+constexpr int TR_BYTES = 16 * TRS * 4;        // one wave's 16-row strip
 
 // SPLITK: the grid is (tiles x splits); block (tile, s) contracts k-steps
 // [s*ksps, min((s+1)*ksps, nt)) and stores its raw fp32 partial tile into slab s
@@ -189,17 +268,40 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
     __syncthreads();   // next stage landed (vmcnt(0)) and everyone is done reading `cur`
   }
 
+  // ---- epilogue.  The accumulators hold 16x16 blocks with 4 columns per lane; stored
+  // as they are, one wave instruction touches 16 rows x 32..64 B (16 partial lines) and
+  // the tile's store tail is issue-bound (~8 B/clk/CU measured).  Instead each wave
+  // transposes one 16-row x 64-column strip at a time through a PRIVATE 4.25-KiB LDS
+  // strip (the stage buffers are free after the last barrier; same-wave DS ops execute
+  // in order, so no barrier is needed) and then reads, post-processes and stores whole
+  // rows: every global access of the epilogue (C, C2, R, AUX) is 16 B per lane and
+  // covers full 128-B lines.
+  constexpr int W = sizeof(TC) == 2 ? 8 : 4;       // columns per lane in the row pass
+  constexpr int LPR = 64 / W;                      // lanes per 64-column row
+  constexpr int RPI = 64 / LPR;                    // rows per wave instruction
+  float* tr = reinterpret_cast<float*>(smem + wave * TR_BYTES);
   const int lr = lane & 15, lg = lane >> 4;
+  const int rr = lane / LPR, rc = (lane % LPR) * W;
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi) {
-    const int64_t m = m0 + wm * 128 + mi * 16 + lr;
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int64_t n = n0 + wn * 64 + ni * 16 + lg * 4;
+    for (int ni = 0; ni < 4; ++ni)
+      *reinterpret_cast<f32x4*>(tr + lr * TRS + ni * 16 + lg * 4) = acc[ni][mi];
+#pragma unroll
+    for (int j = 0; j < 16 / RPI; ++j) {
+      const int row = j * RPI + rr;
+      float v[W];
+#pragma unroll
+      for (int q = 0; q < W / 4; ++q) {
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(tr + row * TRS + rc + 4 * q);
+        v[4 * q] = t4[0]; v[4 * q + 1] = t4[1]; v[4 * q + 2] = t4[2]; v[4 * q + 3] = t4[3];
+      }
+      const int64_t m = m0 + wm * 128 + mi * 16 + row;
+      const int64_t n = n0 + wn * 64 + rc;
       if constexpr (SPLITK)
-        *reinterpret_cast<f32x4*>(ws + ((int64_t)split * g.M + m) * g.N + n) = acc[ni][mi];
+        storev<float, W>(ws + ((int64_t)split * g.M + m) * g.N + n, v);
       else
-        epi_store4<MODE, TC>(g.e, m, n, acc[ni][mi]);
+        epi_row<MODE, TC, W>(g.e, m, n, v);
     }
   }
 }
@@ -214,7 +316,8 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, E
     const int64_t m = i / n4, n = (i % n4) * 4;
     f32x4 acc = *reinterpret_cast<const f32x4*>(ws + m * N + n);
     for (int s = 1; s < splits; ++s) acc += *reinterpret_cast<const f32x4*>(ws + ((int64_t)s * M + m) * N + n);
-    epi_store4<VITMI_EPI_STORE, float>(e, m, n, acc);
+    float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+    epi_row<VITMI_EPI_STORE, float, 4>(e, m, n, v);
   }
 }
 

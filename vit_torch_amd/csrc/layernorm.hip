@@ -17,8 +17,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, i
                                                      float* __restrict__ rstd_out,
                                                      int64_t M, int D, float eps) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t row = (int64_t)blockIdx.x * 4 + w;
-  if (row >= M) return;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < M; row += (int64_t)gridDim.x * 4) {
   const TX* xr = x + row * xs;
   f32x4 v[LN_MAXV];
   float s = 0.f;
@@ -58,6 +57,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, i
       for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
       store4<TY>(yr + c, o);
     }
+  }
   }
 }
 
@@ -167,7 +167,11 @@ extern "C" int vitmi_layernorm_fwd(const void* x, int x_dtype, int64_t x_stride,
   VITMI_REQUIRE(y_stride % 4 == 0 && is_aligned(y, 4 * dtype_size(y_dtype)) && is_aligned(gamma, 16) && is_aligned(beta, 16),
                 VITMI_E_ALIGN, "layernorm_fwd: y/gamma/beta alignment");
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  dim3 grid((unsigned)((M + 3) / 4)), block(256);
+  // grid-stride over rows: 8 blocks per CU keep the loads of several rows in flight per
+  // SIMD without paying a workgroup launch per 4 rows
+  int64_t nblk = (M + 3) / 4;
+  if (nblk > 2048) nblk = 2048;
+  dim3 grid((unsigned)nblk), block(256);
 #define LN_FWD(TX, TY)                                                                        \
   hipLaunchKernelGGL((ln_fwd_kernel<TX, TY>), grid, block, 0, stream, (const TX*)x, x_stride, \
                      gamma, beta, (TY*)y, y_stride, mean, rstd, M, (int)D, eps)
