@@ -4,11 +4,18 @@
 // Layouts: qkv [B, N, 3, H, hd] (output of the qkv Linear), out/dout
 // [B, N, H, hd], lse/delta [B, H, N] fp32.
 //
-// Forward (one wave = 32 query rows, one workgroup = 4 waves = 128 rows of one
-// (b, h); K/V tiles of 64 keys staged in LDS):
+// Work split: one wave = 32 rows (queries; keys in dkdv); a workgroup has
+// NW = ceil(min(N,256)/32) waves (7 for the 197-token ViT-B/16 sequence: 88 %
+// of the padded rows are real, against 77 % with fixed 128-row blocks); the
+// other side streams through LDS in chunks of up to 128 rows that are
+// PREFETCHED INTO REGISTERS while the previous chunk is being computed and
+// committed to LDS between two barriers (split stage, guide T14).
+//
+// Forward:
 //   S^T[key][q] = K·Q^T        A = K rows (ds_read_b128), B = Q rows (registers)
-//   online softmax over keys   the query is on the LANE, so max/sum/rescale are
-//                              lane-local (+1 cross-half shuffle)
+//   online softmax per 32 keys the query is on the LANE, so max/sum/rescale are
+//                              lane-local (+1 cross-half shuffle); O is rescaled
+//                              only when some row's running max actually moved
 //   O^T[d][q]  += V^T·P^T      A = V^T via ds_read_b64_tr_b16, B = the S^T
 //                              accumulator itself re-used as operand (guide §3,
 //                              "An accumulator tile as the next MFMA's operand")
@@ -17,12 +24,15 @@
 //         dV^T += dO^T·P, dK^T += Q^T·dS
 //   dq:   wave = 32 queries, S^T, dP^T (query on the lane), dQ^T += K^T·dS^T
 // 7 MFMA products instead of the minimal 5, but no dQ reduction across waves.
+// hd = 64: the softmax's VALU work (exp, max, sum, cvt) outweighs the MFMAs, so
+// masks are applied only to ragged blocks and the scale is folded into exp2.
 #include "common.h"
 
 namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
+constexpr int CHUNK_MAX = 128;     // rows of the streamed side resident in LDS
 
 __device__ __forceinline__ bf16x4 ds_read_tr16(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, p));
@@ -45,21 +55,32 @@ __device__ __forceinline__ bf16x8 load_tr_frag(const char* img, int stride, int 
   return r;
 }
 
-// stage ROWS rows x HD bf16 from global (token stride `ts` elements) into LDS
-// rows of SB bytes; rows >= N are zero-filled
-template <int HD, int ROWS, int SB>
-__device__ __forceinline__ void stage_rows(char* lds, const bf16* g, int64_t ts, int row0, int N,
-                                           int tid) {
+// split stage: global -> registers (issued early) ... registers -> LDS (after the barrier).
+// `rows` rows x HD bf16 starting at row0 (token stride ts); rows >= N read as zero.
+// A block of nthr threads moves rows*HD/8 16-byte pieces, at most 4 per thread.
+template <int HD>
+__device__ __forceinline__ void prefetch_rows(bf16x8 (&r)[4], const bf16* g, int64_t ts, int row0,
+                                              int rows, int N, int tid, int nthr) {
   constexpr int CPR = HD / 8;
 #pragma unroll
-  for (int c = tid; c < ROWS * CPR; c += 256) {
-    const int r = c / CPR, cc = c % CPR;
-    const int gr = row0 + r;
-    bf16x8 v;
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + i * nthr;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
-    if (gr < N) v = *reinterpret_cast<const bf16x8*>(g + (int64_t)gr * ts + cc * 8);
-    *reinterpret_cast<bf16x8*>(lds + r * SB + cc * 16) = v;
+    for (int e = 0; e < 8; ++e) r[i][e] = (bf16)0.f;
+    if (c < rows * CPR) {
+      const int gr = row0 + c / CPR;
+      if (gr < N) r[i] = *reinterpret_cast<const bf16x8*>(g + (int64_t)gr * ts + (c % CPR) * 8);
+    }
+  }
+}
+template <int HD, int SB>
+__device__ __forceinline__ void commit_rows(char* lds, const bf16x8 (&r)[4], int rows, int tid,
+                                            int nthr) {
+  constexpr int CPR = HD / 8;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + i * nthr;
+    if (c < rows * CPR) *reinterpret_cast<bf16x8*>(lds + (c / CPR) * SB + (c % CPR) * 16) = r[i];
   }
 }
 
@@ -77,6 +98,11 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int base) {
   return r;
 }
 
+__device__ __forceinline__ void zero16(f32x16& v) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = 0.f;
+}
+
 template <int HD>
 __device__ __forceinline__ void store_T_tile(bf16* dst_row, const f32x16 (&acc)[HD / 32], float mul,
                                              int h5) {
@@ -92,24 +118,29 @@ __device__ __forceinline__ void store_T_tile(bf16* dst_row, const f32x16 (&acc)[
     }
 }
 
+// rows owned per workgroup / rows streamed per chunk for a block of nw waves
+__device__ __forceinline__ int chunk_rows(int nw) { return 32 * (nw < 4 ? nw : 4); }
+
 // ------------------------------------------------------------- forward ---
 template <int HD>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv,
+__global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16* __restrict__ qkv,
                                                        bf16* __restrict__ out,
                                                        float* __restrict__ lse, int N, int H,
                                                        float scale_log2e) {
   using C = AttnCfg<HD>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Kl = smem;
-  char* Vl = smem + 64 * C::KS;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  char* Vl = smem + CHUNK_MAX * C::KS;
+  const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
   const int lr = lane & 31, h5 = lane >> 5;
   const int bh = blockIdx.y, b = bh / H, h = bh % H;
   const int64_t ts = (int64_t)3 * H * HD;
   const bf16* qb = qkv + (int64_t)b * N * ts + h * HD;
   const bf16* kb_ = qb + H * HD;
   const bf16* vb = qb + 2 * H * HD;
-  const int q0 = blockIdx.x * 128 + w * 32;
+  const int q0 = blockIdx.x * (32 * nw) + w * 32;
+  const bool active = q0 < N;                 // wave-uniform: this wave owns >= 1 real query
   const int qrow = min(q0 + lr, N - 1);
 
   bf16x8 qf[C::KSTEPS];
@@ -119,70 +150,73 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 
   f32x16 o[C::DB];
 #pragma unroll
-  for (int db = 0; db < C::DB; ++db)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+  for (int db = 0; db < C::DB; ++db) zero16(o[db]);
   float m = -INFINITY, l = 0.f;
 
-  const int nkt = (N + 63) / 64;
-  for (int kt = 0; kt < nkt; ++kt) {
+  const int CK = chunk_rows(nw);
+  const int nck = (N + CK - 1) / CK;
+  bf16x8 kr[4], vr[4];
+  prefetch_rows<HD>(kr, kb_, ts, 0, CK, N, tid, nthr);
+  prefetch_rows<HD>(vr, vb, ts, 0, CK, N, tid, nthr);
+  for (int c = 0; c < nck; ++c) {
+    __syncthreads();                           // everyone is done reading the previous chunk
+    commit_rows<HD, C::KS>(Kl, kr, CK, tid, nthr);
+    commit_rows<HD, C::VS>(Vl, vr, CK, tid, nthr);
     __syncthreads();
-    stage_rows<HD, 64, C::KS>(Kl, kb_, ts, kt * 64, N, tid);
-    stage_rows<HD, 64, C::VS>(Vl, vb, ts, kt * 64, N, tid);
-    __syncthreads();
-
-    f32x16 s[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+    if (c + 1 < nck) {                         // in flight while this chunk is computed
+      prefetch_rows<HD>(kr, kb_, ts, (c + 1) * CK, CK, N, tid, nthr);
+      prefetch_rows<HD>(vr, vb, ts, (c + 1) * CK, CK, N, tid, nthr);
+    }
+    if (!active) continue;
+    const int left = N - c * CK;
+    const int nsb = ((left < CK ? left : CK) + 31) >> 5;
+#pragma unroll 1
+    for (int sb = 0; sb < nsb; ++sb) {
+      f32x16 s;
+      zero16(s);
 #pragma unroll
       for (int ks = 0; ks < C::KSTEPS; ++ks) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Kl + (kb * 32 + lr) * C::KS + (16 * ks + 8 * h5) * 2);
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s[kb], 0, 0, 0);
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Kl + (sb * 32 + lr) * C::KS + (16 * ks + 8 * h5) * 2);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s, 0, 0, 0);
       }
-    }
-    float tmax = -INFINITY;
+      const int key0 = c * CK + sb * 32;
+      if (key0 + 32 > N) {                     // ragged block only: mask keys >= N
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+        for (int r = 0; r < 16; ++r)
+          if (key0 + mfma32_row(r, h5) >= N) s[r] = -INFINITY;
+      }
+      float tmax = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+#pragma unroll
+      for (int r = 4; r < 16; r += 2) tmax = fmaxf(tmax, fmaxf(s[r], s[r + 1]));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const float m_new = fmaxf(m, tmax * scale_log2e);
+      if (!__all(m_new == m)) {                // some row's max moved: rescale once
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+        l *= alpha;
+#pragma unroll
+        for (int db = 0; db < C::DB; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        m = m_new;
+      }
+      float psum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = kt * 64 + kb * 32 + mfma32_row(r, h5);
-        const float v = key < N ? s[kb][r] * scale_log2e : -INFINITY;
-        s[kb][r] = v;
-        tmax = fmaxf(tmax, v);
-      }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-    const float m_new = fmaxf(m, tmax);
-    const float alpha = exp2f(m - m_new);
-    float psum = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = exp2f(s[kb][r] - m_new);
-        s[kb][r] = p;
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -m));
+        s[r] = p;
         psum += p;
       }
-    psum += __shfl_xor(psum, 32);
-    l = l * alpha + psum;
-    m = m_new;
-#pragma unroll
-    for (int db = 0; db < C::DB; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      l += psum + __shfl_xor(psum, 32);
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 pf = pack8(s[kb], 8 * s2);
+        const bf16x8 pf = pack8(s, 8 * s2);
 #pragma unroll
         for (int db = 0; db < C::DB; ++db) {
-          const bf16x8 a = load_tr_frag(Vl, C::VS, kb * 32 + 16 * s2, db * 32, lane);
+          const bf16x8 a = load_tr_frag(Vl, C::VS, sb * 32 + 16 * s2, db * 32, lane);
           o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf, o[db], 0, 0, 0);
         }
       }
+    }
   }
 
   const int q = q0 + lr;
@@ -221,7 +255,7 @@ __global__ void attn_delta_kernel(const bf16* __restrict__ out, const bf16* __re
 
 // ------------------------------------------------- backward: dK and dV ---
 template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16* __restrict__ qkv,
+__global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(const bf16* __restrict__ qkv,
                                                             const bf16* __restrict__ dout,
                                                             const float* __restrict__ lse,
                                                             const float* __restrict__ delta,
@@ -231,10 +265,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16* __restri
   constexpr int QS = C::KS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ql = smem;
-  char* dOl = smem + 32 * QS;
-  float* lse_s = reinterpret_cast<float*>(smem + 64 * QS);
-  float* del_s = lse_s + 32;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  char* dOl = smem + CHUNK_MAX * QS;
+  float* lse_s = reinterpret_cast<float*>(smem + 2 * CHUNK_MAX * QS);
+  float* del_s = lse_s + CHUNK_MAX;
+  const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
   const int lr = lane & 31, h5 = lane >> 5;
   const int bh = blockIdx.y, b = bh / H, h = bh % H;
   const int64_t ts = (int64_t)3 * H * HD;
@@ -243,7 +278,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16* __restri
   const bf16* kb_ = qb + H * HD;
   const bf16* vb = qb + 2 * H * HD;
   const bf16* dob = dout + (int64_t)b * N * os + h * HD;
-  const int key0 = blockIdx.x * 128 + w * 32;
+  const int key0 = blockIdx.x * (32 * nw) + w * 32;
+  const bool active = key0 < N;
   const int krow = min(key0 + lr, N - 1);
 
   bf16x8 kf[C::KSTEPS], vf[C::KSTEPS];
@@ -254,53 +290,70 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16* __restri
   }
   f32x16 dk[C::DB], dv[C::DB];
 #pragma unroll
-  for (int db = 0; db < C::DB; ++db)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+  for (int db = 0; db < C::DB; ++db) { zero16(dk[db]); zero16(dv[db]); }
 
-  const int nqt = (N + 31) / 32;
-  for (int qt = 0; qt < nqt; ++qt) {
+  const int CK = chunk_rows(nw);
+  const int nck = (N + CK - 1) / CK;
+  bf16x8 qr[4], dr[4];
+  prefetch_rows<HD>(qr, qb, ts, 0, CK, N, tid, nthr);
+  prefetch_rows<HD>(dr, dob, os, 0, CK, N, tid, nthr);
+  for (int c = 0; c < nck; ++c) {
     __syncthreads();
-    stage_rows<HD, 32, QS>(Ql, qb, ts, qt * 32, N, tid);
-    stage_rows<HD, 32, QS>(dOl, dob, os, qt * 32, N, tid);
-    if (tid < 32) {
-      const int q = qt * 32 + tid;
-      lse_s[tid] = q < N ? lse[(int64_t)bh * N + q] * LOG2E : INFINITY;
+    commit_rows<HD, QS>(Ql, qr, CK, tid, nthr);
+    commit_rows<HD, QS>(dOl, dr, CK, tid, nthr);
+    if (tid < CK) {
+      const int q = c * CK + tid;
+      lse_s[tid] = q < N ? lse[(int64_t)bh * N + q] * LOG2E : INFINITY;   // +inf -> p = 0 for padded queries
       del_s[tid] = q < N ? delta[(int64_t)bh * N + q] : 0.f;
     }
     __syncthreads();
-
-    f32x16 s, dp;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-    for (int ks = 0; ks < C::KSTEPS; ++ks) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ql + lr * QS + (16 * ks + 8 * h5) * 2);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf[ks], s, 0, 0, 0);
+    if (c + 1 < nck) {
+      prefetch_rows<HD>(qr, qb, ts, (c + 1) * CK, CK, N, tid, nthr);
+      prefetch_rows<HD>(dr, dob, os, (c + 1) * CK, CK, N, tid, nthr);
     }
+    if (!active) continue;
+    const int left = N - c * CK;
+    const int nsb = ((left < CK ? left : CK) + 31) >> 5;
+#pragma unroll 1
+    for (int sb = 0; sb < nsb; ++sb) {
+      f32x16 s, dp;
+      zero16(s);
+      zero16(dp);
 #pragma unroll
-    for (int ks = 0; ks < C::KSTEPS; ++ks) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(dOl + lr * QS + (16 * ks + 8 * h5) * 2);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, vf[ks], dp, 0, 0, 0);
-    }
-    // rows = query index inside the tile, cols (lane) = key
+      for (int ks = 0; ks < C::KSTEPS; ++ks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ql + (sb * 32 + lr) * QS + (16 * ks + 8 * h5) * 2);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf[ks], s, 0, 0, 0);
+      }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int qi = mfma32_row(r, h5);
-      const float p = exp2f(s[r] * scale_log2e - lse_s[qi]);
-      s[r] = p;
-      dp[r] = p * (dp[r] - del_s[qi]);
-    }
+      for (int ks = 0; ks < C::KSTEPS; ++ks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(dOl + (sb * 32 + lr) * QS + (16 * ks + 8 * h5) * 2);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, vf[ks], dp, 0, 0, 0);
+      }
+      // rows = query index inside the sub-block, cols (lane) = key; the row constants
+      // come in runs of 4 consecutive queries: 8*g + 4*h5 + {0..3}
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      const bf16x8 pf = pack8(s, 8 * s2);
-      const bf16x8 dsf = pack8(dp, 8 * s2);
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 ls = *reinterpret_cast<const f32x4*>(lse_s + sb * 32 + 8 * g + 4 * h5);
+        const f32x4 de = *reinterpret_cast<const f32x4*>(del_s + sb * 32 + 8 * g + 4 * h5);
 #pragma unroll
-      for (int db = 0; db < C::DB; ++db) {
-        const bf16x8 a = load_tr_frag(dOl, QS, 16 * s2, db * 32, lane);
-        dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf, dv[db], 0, 0, 0);
-        const bf16x8 a2 = load_tr_frag(Ql, QS, 16 * s2, db * 32, lane);
-        dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, dsf, dk[db], 0, 0, 0);
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -ls[e]));
+          s[r] = p;
+          dp[r] = p * (dp[r] - de[e]);
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = pack8(s, 8 * s2);
+        const bf16x8 dsf = pack8(dp, 8 * s2);
+#pragma unroll
+        for (int db = 0; db < C::DB; ++db) {
+          const bf16x8 a = load_tr_frag(dOl, QS, sb * 32 + 16 * s2, db * 32, lane);
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf, dv[db], 0, 0, 0);
+          const bf16x8 a2 = load_tr_frag(Ql, QS, sb * 32 + 16 * s2, db * 32, lane);
+          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, dsf, dk[db], 0, 0, 0);
+        }
       }
     }
   }
@@ -314,7 +367,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16* __restri
 
 // --------------------------------------------------------- backward: dQ ---
 template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv,
+__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv,
                                                           const bf16* __restrict__ dout,
                                                           const float* __restrict__ lse,
                                                           const float* __restrict__ delta,
@@ -324,8 +377,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
   constexpr int KS = C::KS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Kl = smem;
-  char* Vl = smem + 64 * KS;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  char* Vl = smem + CHUNK_MAX * KS;
+  const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
   const int lr = lane & 31, h5 = lane >> 5;
   const int bh = blockIdx.y, b = bh / H, h = bh % H;
   const int64_t ts = (int64_t)3 * H * HD;
@@ -334,7 +388,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
   const bf16* kb_ = qb + H * HD;
   const bf16* vb = qb + 2 * H * HD;
   const bf16* dob = dout + (int64_t)b * N * os + h * HD;
-  const int q0 = blockIdx.x * 128 + w * 32;
+  const int q0 = blockIdx.x * (32 * nw) + w * 32;
+  const bool active = q0 < N;
   const int qrow = min(q0 + lr, N - 1);
 
   bf16x8 qf[C::KSTEPS], dof[C::KSTEPS];
@@ -347,36 +402,45 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
   const float del_q = delta[(int64_t)bh * N + qrow];
   f32x16 dq[C::DB];
 #pragma unroll
-  for (int db = 0; db < C::DB; ++db)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
+  for (int db = 0; db < C::DB; ++db) zero16(dq[db]);
 
-  const int nkt = (N + 63) / 64;
-  for (int kt = 0; kt < nkt; ++kt) {
+  const int CK = chunk_rows(nw);
+  const int nck = (N + CK - 1) / CK;
+  bf16x8 kr[4], vr[4];
+  prefetch_rows<HD>(kr, kb_, ts, 0, CK, N, tid, nthr);
+  prefetch_rows<HD>(vr, vb, ts, 0, CK, N, tid, nthr);
+  for (int c = 0; c < nck; ++c) {
     __syncthreads();
-    stage_rows<HD, 64, KS>(Kl, kb_, ts, kt * 64, N, tid);
-    stage_rows<HD, 64, KS>(Vl, vb, ts, kt * 64, N, tid);
+    commit_rows<HD, KS>(Kl, kr, CK, tid, nthr);
+    commit_rows<HD, KS>(Vl, vr, CK, tid, nthr);
     __syncthreads();
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    if (c + 1 < nck) {
+      prefetch_rows<HD>(kr, kb_, ts, (c + 1) * CK, CK, N, tid, nthr);
+      prefetch_rows<HD>(vr, vb, ts, (c + 1) * CK, CK, N, tid, nthr);
+    }
+    if (!active) continue;
+    const int left = N - c * CK;
+    const int nsb = ((left < CK ? left : CK) + 31) >> 5;
+#pragma unroll 1
+    for (int sb = 0; sb < nsb; ++sb) {
       f32x16 st, dpt;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
+      zero16(st);
+      zero16(dpt);
 #pragma unroll
       for (int ks = 0; ks < C::KSTEPS; ++ks) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Kl + (kb * 32 + lr) * KS + (16 * ks + 8 * h5) * 2);
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Kl + (sb * 32 + lr) * KS + (16 * ks + 8 * h5) * 2);
         st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], st, 0, 0, 0);
       }
 #pragma unroll
       for (int ks = 0; ks < C::KSTEPS; ++ks) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Vl + (kb * 32 + lr) * KS + (16 * ks + 8 * h5) * 2);
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Vl + (sb * 32 + lr) * KS + (16 * ks + 8 * h5) * 2);
         dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, dof[ks], dpt, 0, 0, 0);
       }
-      // zero-filled K/V rows (key >= N) give finite p and dS, and multiply a
-      // zero K^T row below, so no masking is needed here
+      // zero-filled K/V rows (key >= N) give a finite p and dS that multiply a zero
+      // K^T row below, so no masking is needed
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = exp2f(st[r] * scale_log2e - lse_q);
+        const float p = __builtin_amdgcn_exp2f(fmaf(st[r], scale_log2e, -lse_q));
         st[r] = p * (dpt[r] - del_q);
       }
 #pragma unroll
@@ -384,7 +448,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
         const bf16x8 dsf = pack8(st, 8 * s2);
 #pragma unroll
         for (int db = 0; db < C::DB; ++db) {
-          const bf16x8 a = load_tr_frag(Kl, KS, kb * 32 + 16 * s2, db * 32, lane);
+          const bf16x8 a = load_tr_frag(Kl, KS, sb * 32 + 16 * s2, db * 32, lane);
           dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, dsf, dq[db], 0, 0, 0);
         }
       }
@@ -392,6 +456,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
   }
   const int q = q0 + lr;
   if (q < N) store_T_tile<HD>(dqkv + (int64_t)(b * (int64_t)N + q) * ts + h * HD, dq, scale, h5);
+}
+
+inline int attn_waves(int64_t N) {
+  int64_t nw = ((N < 256 ? N : 256) + 31) / 32;
+  return (int)(nw < 1 ? 1 : nw);
 }
 
 }  // namespace
@@ -416,13 +485,14 @@ extern "C" int vitmi_attn_fwd(const void* qkv, void* out, float* lse, int dtype,
   int rc = check_attn(qkv, dtype, B, N, H, hd, "attn_fwd");
   if (rc) return rc;
   VITMI_REQUIRE(is_aligned(out, 8), VITMI_E_ALIGN, "attn_fwd: out must be 8-B aligned");
-  dim3 grid((unsigned)((N + 127) / 128), (unsigned)(B * H));
+  const int nw = attn_waves(N);
+  dim3 grid((unsigned)((N + 32 * nw - 1) / (32 * nw)), (unsigned)(B * H));
   if (hd == 64) {
-    const size_t lds = 64 * AttnCfg<64>::KS + 64 * AttnCfg<64>::VS;
-    hipLaunchKernelGGL((attn_fwd_kernel<64>), grid, dim3(256), lds, stream, (const bf16*)qkv, (bf16*)out, lse, (int)N, (int)H, scale * LOG2E);
+    const size_t lds = CHUNK_MAX * (AttnCfg<64>::KS + AttnCfg<64>::VS);
+    hipLaunchKernelGGL((attn_fwd_kernel<64>), grid, dim3(64 * nw), lds, stream, (const bf16*)qkv, (bf16*)out, lse, (int)N, (int)H, scale * LOG2E);
   } else {
-    const size_t lds = 64 * AttnCfg<32>::KS + 64 * AttnCfg<32>::VS;
-    hipLaunchKernelGGL((attn_fwd_kernel<32>), grid, dim3(256), lds, stream, (const bf16*)qkv, (bf16*)out, lse, (int)N, (int)H, scale * LOG2E);
+    const size_t lds = CHUNK_MAX * (AttnCfg<32>::KS + AttnCfg<32>::VS);
+    hipLaunchKernelGGL((attn_fwd_kernel<32>), grid, dim3(64 * nw), lds, stream, (const bf16*)qkv, (bf16*)out, lse, (int)N, (int)H, scale * LOG2E);
   }
   return vitmi_check_launch("attn_fwd_kernel");
 }
@@ -444,7 +514,8 @@ extern "C" int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout
   if (rc) return rc;
   VITMI_REQUIRE(is_aligned(out, 16) && is_aligned(dout, 16) && is_aligned(dqkv, 8), VITMI_E_ALIGN, "attn_bwd: out/dout must be 16-B, dqkv 8-B aligned");
   const int64_t rows = B * N * H;
-  dim3 grid((unsigned)((N + 127) / 128), (unsigned)(B * H));
+  const int nw = attn_waves(N);
+  dim3 grid((unsigned)((N + 32 * nw - 1) / (32 * nw)), (unsigned)(B * H));
 #define LAUNCH_BWD(HDV)                                                                                  \
   do {                                                                                                   \
     const int64_t threads = rows * (HDV / 8);                                                            \
@@ -452,13 +523,13 @@ extern "C" int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout
                        stream, (const bf16*)out, (const bf16*)dout, delta, rows, (int)N, (int)H);        \
     rc = vitmi_check_launch("attn_delta_kernel");                                                        \
     if (rc) return rc;                                                                                   \
-    const size_t lds_a = 64 * AttnCfg<HDV>::KS + 64 * sizeof(float);                                     \
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HDV>), grid, dim3(256), lds_a, stream, (const bf16*)qkv,    \
+    const size_t lds_a = 2 * CHUNK_MAX * AttnCfg<HDV>::KS + 2 * CHUNK_MAX * sizeof(float);               \
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HDV>), grid, dim3(64 * nw), lds_a, stream, (const bf16*)qkv, \
                        (const bf16*)dout, lse, delta, (bf16*)dqkv, (int)N, (int)H, scale, scale * LOG2E); \
     rc = vitmi_check_launch("attn_bwd_dkdv_kernel");                                                     \
     if (rc) return rc;                                                                                   \
-    const size_t lds_b = 128 * AttnCfg<HDV>::KS;                                                         \
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<HDV>), grid, dim3(256), lds_b, stream, (const bf16*)qkv,      \
+    const size_t lds_b = 2 * CHUNK_MAX * AttnCfg<HDV>::KS;                                               \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<HDV>), grid, dim3(64 * nw), lds_b, stream, (const bf16*)qkv,  \
                        (const bf16*)dout, lse, delta, (bf16*)dqkv, (int)N, (int)H, scale, scale * LOG2E); \
     rc = vitmi_check_launch("attn_bwd_dq_kernel");                                                       \
   } while (0)
