@@ -1,0 +1,12 @@
+"""Summarise a rocprofv3 --kernel-trace --stats run: per-kernel totals per step."""
+import csv, glob, re, sys
+d = sys.argv[1]; steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+f = glob.glob(d + "/**/*kernel_stats.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+print(f"total kernel time {tot/1e6:.2f} ms over {steps:g} steps = {tot/1e6/steps:.2f} ms/step")
+print(f"{'ms/step':>9} {'calls/step':>10} {'avg us':>9} {'%':>6}  kernel")
+for r in rows[:int(sys.argv[3]) if len(sys.argv) > 3 else 28]:
+    n = re.sub(r"\(anonymous namespace\)::", "", r["Name"])
+    n = re.sub(r"_ZN12_GLOBAL__N_1\d+", "", n)[:100]
+    print(f"{float(r['TotalDurationNs'])/1e6/steps:9.3f} {int(r['Calls'])/steps:10.1f} {float(r['AverageNs'])/1e3:9.1f} {float(r['Percentage']):6.2f}  {n}")

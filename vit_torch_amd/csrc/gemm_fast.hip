@@ -22,6 +22,7 @@
 // Block -> tile map is XCD-aware (8 XCDs, private L2s): each XCD walks a
 // contiguous run of tiles, n fastest, so the A panel of a row of tiles and the
 // whole weight matrix stay in that XCD's L2.
+#include <cstdlib>
 #include "epilogue.h"
 
 namespace {
@@ -86,6 +87,64 @@ __device__ __forceinline__ bf16x8 load_frag(const char* tile, int rb, int kh, in
   }
 }
 
+// ---- PIPE=1 building blocks: 32-deep k-slabs (A slab 16 KiB + B slab 16 KiB)
+constexpr int SLAB_BYTES = 256 * 32 * 2;      // one operand slab
+constexpr int RING_STAGE = 2 * SLAB_BYTES;    // A slab | B slab
+template <bool KM>
+__device__ __forceinline__ void stage_slab(char* slab, const bf16* __restrict__ X, int64_t ld,
+                                           int64_t r0, int64_t k0, int wave, int lane) {
+  if constexpr (KM) {       // 16 subtiles of 16 rows x 32 k; this wave fills subtiles 2w, 2w+1
+    const int pb = 16 * lane;
+    const int lb = pb ^ (((pb >> 9) & 1) << 5);
+    const int row = lb >> 6, ch = (lb & 63) >> 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int st = wave * 2 + i;
+      glds16(X + (r0 + st * 16 + row) * ld + k0 + ch * 8, slab + st * 1024);
+    }
+  } else {                  // 32 k-rows of 512 B; this wave fills row pairs 2w, 2w+1
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int j = wave * 2 + i;
+      const int row = 2 * j + (lane >> 5);
+      const int pc16 = lane & 31;
+      const int key = (row & 3) | (((row >> 3) & 1) << 2);
+      const int c32 = (pc16 >> 1) ^ key;
+      glds16(X + (k0 + row) * ld + r0 + c32 * 16 + (pc16 & 1) * 8, slab + j * 1024);
+    }
+  }
+}
+template <bool KM>
+__device__ __forceinline__ bf16x8 slab_frag(const char* slab, int rb, int lane) {
+  if constexpr (KM) {
+    int pb = (lane & 15) * 64 + (lane >> 4) * 16;
+    pb ^= ((pb >> 9) & 1) << 5;
+    return *reinterpret_cast<const bf16x8*>(slab + rb * 1024 + pb);
+  } else {
+    const int g = lane >> 4, i = lane & 15;
+    const int row = 8 * g + (i >> 2);
+    const int key = (row & 3) | (((row >> 3) & 1) << 2);
+    const char* p = slab + row * 512 + ((rb ^ key) * 32) + 8 * (i & 3);
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, p));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, p + 4 * 512));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+  }
+}
+// all but the `n` youngest of this wave's vector-memory ops (LDS-DMA included) are done
+__device__ __forceinline__ void wait_vm(int n) {
+  if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void raw_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // ---- fast GELU for the bf16 epilogues: erf by Abramowitz-Stegun 7.1.26
 // (|abs err| <= 1.5e-7, far below bf16 resolution); ONE exp serves both the erf
 // tail and the Gaussian pdf, so gelu' costs no second transcendental.  The fp32
@@ -134,12 +193,12 @@ __device__ __forceinline__ void storev(T* p, const float (&v)[W]) {
 }
 
 // epilogue on W consecutive columns n.. of row m; v = raw accumulators in, stored out
+// b / gm: bias and LayerScale of the lane's W columns (the same for every row, so the
+// caller loads them ONCE: a load inside the row loop would put a vmcnt wait, which also
+// counts the previous rows' stores, in front of every store)
 template <int MODE, typename TC, int W>
-__device__ __forceinline__ void epi_row(const EpiArgs& e, int64_t m, int64_t n, float (&v)[W]) {
-  float b[W];
-#pragma unroll
-  for (int i = 0; i < W; ++i) b[i] = 0.f;
-  if (e.bias) loadv<float, W>(e.bias + n, b);
+__device__ __forceinline__ void epi_row(const EpiArgs& e, int64_t m, int64_t n, float (&v)[W],
+                                        const float (&b)[W], const float (&gm)[W]) {
   TC* C = reinterpret_cast<TC*>(e.C);
   if constexpr (MODE == VITMI_EPI_STORE) {
 #pragma unroll
@@ -166,15 +225,8 @@ __device__ __forceinline__ void epi_row(const EpiArgs& e, int64_t m, int64_t n, 
   } else if constexpr (MODE == VITMI_EPI_RESIDUAL) {
     float r[W];
     loadv<TC, W>(reinterpret_cast<const TC*>(e.R) + m * e.ldr + n, r);
-    if (e.gamma) {
-      float gm[W];
-      loadv<float, W>(e.gamma + n, gm);
 #pragma unroll
-      for (int i = 0; i < W; ++i) v[i] = r[i] + gm[i] * (v[i] + b[i]);
-    } else {
-#pragma unroll
-      for (int i = 0; i < W; ++i) v[i] = r[i] + (v[i] + b[i]);
-    }
+    for (int i = 0; i < W; ++i) v[i] = r[i] + gm[i] * (v[i] + b[i]);
   } else if constexpr (MODE == VITMI_EPI_DGELU) {
     float a[W];
     loadv<bf16, W>(reinterpret_cast<const bf16*>(e.AUX) + m * e.ldaux + n, a);
@@ -209,7 +261,19 @@ constexpr int TR_BYTES = 16 * TRS * 4;        // one wave's 16-row strip
 // of `ws` ([splits][M][N]); splitk_reduce_kernel sums the slabs in a fixed order
 // (deterministic) and applies the epilogue.  Used for the weight gradients,
 // whose output is only 9-48 tiles while the contraction runs over all M tokens.
-template <bool A_KM, bool B_KM, int MODE, typename TC, bool SPLITK = false>
+//
+// PIPE = 1 main loop: a 4-stage ring of 32-deep k-slabs and the 8 waves split into two
+// groups (wm = 0 / 1; waves w and w+4 share a SIMD) that run ONE BARRIER APART: every
+// barrier interval one group is in its R phase (12 fragment reads of slab j + the 4
+// LDS-DMA instructions of slab j+3) while the other is in its M phase (32 MFMAs), so
+// each SIMD's matrix pipe always has a wave issuing MFMAs while its partner moves
+// data.  Slab j sits in stage j&3; group 0 reads it in interval 2j, group 1 in 2j+1,
+// so stage (j-1)&3 is free again at R(j) and is refilled with slab j+3, which is first
+// read three slabs (>= 5 intervals) later: the DMA never has to be waited for in
+// steady state, and the counted vmcnt (8 = two younger slabs may still be in flight)
+// before the barrier that precedes the first read orders it (guide: "Read a staged
+// buffer one phase AFTER the wait that retires it").
+template <bool A_KM, bool B_KM, int MODE, typename TC, bool SPLITK = false, int PIPE = 0>
 __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int tiles_n, int nwg,
                                                              int ntiles, int ksps, float* ws) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (A tile | B tile)
@@ -239,6 +303,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
   const int nt_all = (int)(g.K / BK);
   const int kt0 = SPLITK ? split * ksps : 0;
   const int nt = SPLITK ? min(ksps, nt_all - kt0) : nt_all;
+  if constexpr (PIPE == 0) {
   stage_tile<A_KM>(smem, A, g.lda, m0, (int64_t)kt0 * BK, wave, lane);
   stage_tile<B_KM>(smem + TILE_BYTES, B, g.ldb, n0, (int64_t)kt0 * BK, wave, lane);
   __syncthreads();
@@ -268,6 +333,49 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
     __syncthreads();   // next stage landed (vmcnt(0)) and everyone is done reading `cur`
   }
 
+  } else {
+    const int ns = 2 * nt;                         // 32-deep slabs
+    const int64_t kb0 = (int64_t)kt0 * BK;
+    const int grp = wm;                            // 0: leads, 1: one barrier behind
+    auto issue = [&](int j) {
+      char* st = smem + (j & 3) * RING_STAGE;
+      stage_slab<A_KM>(st, A, g.lda, m0, kb0 + (int64_t)j * 32, wave, lane);
+      stage_slab<B_KM>(st + SLAB_BYTES, B, g.ldb, n0, kb0 + (int64_t)j * 32, wave, lane);
+    };
+    issue(0);
+    issue(1);
+    if (ns > 2) issue(2);
+    wait_vm(ns > 2 ? 8 : 4);                       // slab 0 has landed
+    raw_barrier();                                 // b0
+    if (grp == 1) raw_barrier();                   // stagger
+#pragma unroll 1
+    for (int j = 0; j < ns; ++j) {
+      // ---- R(j)
+      if (j + 3 < ns) issue(j + 3);
+      const char* As = smem + (j & 3) * RING_STAGE;
+      const char* Bs = As + SLAB_BYTES;
+      bf16x8 bf[4], af[8];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) bf[ni] = slab_frag<B_KM>(Bs, wn * 4 + ni, lane);
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) af[mi] = slab_frag<A_KM>(As, wm * 8 + mi, lane);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of this stage are complete
+      const int rem = ns - 2 - j;                   // slabs younger than j+1 already issued
+      if (grp == 1) wait_vm(rem >= 2 ? 8 : (rem == 1 ? 4 : 0));
+      raw_barrier();
+      // ---- M(j)
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      if (grp == 0) wait_vm(rem >= 2 ? 8 : (rem == 1 ? 4 : 0));
+      if (!(grp == 1 && j == ns - 1)) raw_barrier();
+    }
+  }
+
   // ---- epilogue.  The accumulators hold 16x16 blocks with 4 columns per lane; stored
   // as they are, one wave instruction touches 16 rows x 32..64 B (16 partial lines) and
   // the tile's store tail is issue-bound (~8 B/clk/CU measured).  Instead each wave
@@ -282,6 +390,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
   float* tr = reinterpret_cast<float*>(smem + wave * TR_BYTES);
   const int lr = lane & 15, lg = lane >> 4;
   const int rr = lane / LPR, rc = (lane % LPR) * W;
+  float bias_r[W], gamma_r[W];
+#pragma unroll
+  for (int i = 0; i < W; ++i) { bias_r[i] = 0.f; gamma_r[i] = 1.f; }
+  if constexpr (!SPLITK) {
+    if (g.e.bias) loadv<float, W>(g.e.bias + n0 + wn * 64 + rc, bias_r);
+    if (MODE == VITMI_EPI_RESIDUAL && g.e.gamma) loadv<float, W>(g.e.gamma + n0 + wn * 64 + rc, gamma_r);
+  }
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi) {
 #pragma unroll
@@ -301,7 +416,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
       if constexpr (SPLITK)
         storev<float, W>(ws + ((int64_t)split * g.M + m) * g.N + n, v);
       else
-        epi_row<MODE, TC, W>(g.e, m, n, v);
+        epi_row<MODE, TC, W>(g.e, m, n, v, bias_r, gamma_r);
     }
   }
 }
@@ -317,7 +432,10 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, E
     f32x4 acc = *reinterpret_cast<const f32x4*>(ws + m * N + n);
     for (int s = 1; s < splits; ++s) acc += *reinterpret_cast<const f32x4*>(ws + ((int64_t)s * M + m) * N + n);
     float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-    epi_row<VITMI_EPI_STORE, float, 4>(e, m, n, v);
+    float b[4] = {0.f, 0.f, 0.f, 0.f};
+    const float one[4] = {1.f, 1.f, 1.f, 1.f};
+    if (e.bias) loadv<float, 4>(e.bias + n, b);
+    epi_row<VITMI_EPI_STORE, float, 4>(e, m, n, v, b, one);
   }
 }
 
@@ -334,15 +452,32 @@ inline void splitk_plan(int tiles, int nt, int* splits, int* ksps) {
   *splits = (nt + k - 1) / k;
 }
 
+static int pipe_mode() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("VITMI_GEMM_PIPE");
+    mode = (e && e[0] == '0') ? 0 : 1;
+  }
+  return mode;
+}
+
+template <bool A_KM, bool B_KM, int MODE, typename TC, int PIPE>
+int launch_p(const GemmArgs& g, hipStream_t stream);
+
 template <bool A_KM, bool B_KM, int MODE, typename TC>
 int launch(const GemmArgs& g, hipStream_t stream) {
+  return pipe_mode() ? launch_p<A_KM, B_KM, MODE, TC, 1>(g, stream) : launch_p<A_KM, B_KM, MODE, TC, 0>(g, stream);
+}
+
+template <bool A_KM, bool B_KM, int MODE, typename TC, int PIPE>
+int launch_p(const GemmArgs& g, hipStream_t stream) {
   const int tiles_m = (int)(g.M / BM), tiles_n = (int)(g.N / BN);
   const int nwg = tiles_m * tiles_n;
   if constexpr (MODE == VITMI_EPI_STORE && sizeof(TC) == 4) {
     int splits, ksps;
     splitk_plan(nwg, (int)(g.K / BK), &splits, &ksps);
     if (splits > 1 && g.ws && g.ws_bytes >= (size_t)splits * g.M * g.N * sizeof(float)) {
-      auto kern = gemm_fast_kernel<A_KM, B_KM, MODE, TC, true>;
+      auto kern = gemm_fast_kernel<A_KM, B_KM, MODE, TC, true, PIPE>;
       static bool attr_set_sk = false;
       if (!attr_set_sk) {
         hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
@@ -360,7 +495,7 @@ int launch(const GemmArgs& g, hipStream_t stream) {
       return vitmi_check_launch("splitk_reduce_kernel");
     }
   }
-  auto kern = gemm_fast_kernel<A_KM, B_KM, MODE, TC, false>;
+  auto kern = gemm_fast_kernel<A_KM, B_KM, MODE, TC, false, PIPE>;
   static bool attr_set = false;   // per instantiation
   if (!attr_set) {
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
