@@ -90,41 +90,68 @@ __device__ __forceinline__ bf16x8 load_frag(const char* tile, int rb, int kh, in
 // ---- PIPE=1 building blocks: 32-deep k-slabs (A slab 16 KiB + B slab 16 KiB)
 constexpr int SLAB_BYTES = 256 * 32 * 2;      // one operand slab
 constexpr int RING_STAGE = 2 * SLAB_BYTES;    // A slab | B slab
-template <bool KM>
-__device__ __forceinline__ void stage_slab(char* slab, const bf16* __restrict__ X, int64_t ld,
-                                           int64_t r0, int64_t k0, int wave, int lane) {
-  if constexpr (KM) {       // 16 subtiles of 16 rows x 32 k; this wave fills subtiles 2w, 2w+1
-    const int pb = 16 * lane;
-    const int lb = pb ^ (((pb >> 9) & 1) << 5);
-    const int row = lb >> 6, ch = (lb & 63) >> 4;
+// Per-wave staging plan of one operand: two LDS-DMA instructions per slab.  Everything
+// that depends on the lane is folded into a 32-bit byte offset computed ONCE, everything
+// else into a wave-uniform base pointer that advances by a constant per slab, so issuing
+// a slab costs scalar adds + 2 global_load_lds per operand (no per-slab VALU address math:
+// the R phase must stay shorter than the partner's 32-MFMA M phase).
+template <bool KM> struct SlabPlan {
+  const char* base[2];     // wave-uniform
+  uint32_t off[2];         // per lane
+  int64_t step;            // bytes per 32-deep slab
+  __device__ __forceinline__ void init(const bf16* X, int64_t ld, int64_t r0, int64_t k0, int wave, int lane) {
+    if constexpr (KM) {    // 16 subtiles of 16 rows x 32 k; this wave fills subtiles 2w, 2w+1
+      const int pb = 16 * lane;
+      const int lb = pb ^ (((pb >> 9) & 1) << 5);
+      const int row = lb >> 6, ch = (lb & 63) >> 4;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int st = wave * 2 + i;
-      glds16(X + (r0 + st * 16 + row) * ld + k0 + ch * 8, slab + st * 1024);
-    }
-  } else {                  // 32 k-rows of 512 B; this wave fills row pairs 2w, 2w+1
+      for (int i = 0; i < 2; ++i) {
+        const int st = wave * 2 + i;
+        base[i] = reinterpret_cast<const char*>(X + (r0 + st * 16) * ld + k0);
+        off[i] = (uint32_t)((row * ld + ch * 8) * 2);
+      }
+      step = 64;
+    } else {               // 32 k-rows of 512 B; this wave fills row pairs 2w, 2w+1
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int j = wave * 2 + i;
-      const int row = 2 * j + (lane >> 5);
-      const int pc16 = lane & 31;
-      const int key = (row & 3) | (((row >> 3) & 1) << 2);
-      const int c32 = (pc16 >> 1) ^ key;
-      glds16(X + (k0 + row) * ld + r0 + c32 * 16 + (pc16 & 1) * 8, slab + j * 1024);
+      for (int i = 0; i < 2; ++i) {
+        const int jj = wave * 2 + i;
+        const int row = 2 * jj + (lane >> 5);
+        const int pc16 = lane & 31;
+        const int key = (row & 3) | (((row >> 3) & 1) << 2);
+        const int c32 = (pc16 >> 1) ^ key;
+        base[i] = reinterpret_cast<const char*>(X + (k0 + 2 * jj) * ld + r0);
+        off[i] = (uint32_t)(((lane >> 5) * ld + c32 * 16 + (pc16 & 1) * 8) * 2);
+      }
+      step = 64 * ld;
     }
   }
-}
+  __device__ __forceinline__ void issue(char* slab, int j, int wave) const {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      glds16(base[i] + (int64_t)j * step + off[i], slab + (wave * 2 + i) * 1024);
+  }
+};
+
+// per-lane LDS byte offset of the fragment of block rb inside a slab (loop invariant)
 template <bool KM>
-__device__ __forceinline__ bf16x8 slab_frag(const char* slab, int rb, int lane) {
+__device__ __forceinline__ uint32_t frag_off(int rb, int lane) {
   if constexpr (KM) {
     int pb = (lane & 15) * 64 + (lane >> 4) * 16;
     pb ^= ((pb >> 9) & 1) << 5;
-    return *reinterpret_cast<const bf16x8*>(slab + rb * 1024 + pb);
+    return (uint32_t)(rb * 1024 + pb);
   } else {
     const int g = lane >> 4, i = lane & 15;
     const int row = 8 * g + (i >> 2);
     const int key = (row & 3) | (((row >> 3) & 1) << 2);
-    const char* p = slab + row * 512 + ((rb ^ key) * 32) + 8 * (i & 3);
+    return (uint32_t)(row * 512 + ((rb ^ key) * 32) + 8 * (i & 3));
+  }
+}
+template <bool KM>
+__device__ __forceinline__ bf16x8 slab_frag(const char* slab, uint32_t off) {
+  if constexpr (KM) {
+    return *reinterpret_cast<const bf16x8*>(slab + off);
+  } else {
+    const char* p = slab + off;
     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, p));
     const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, p + 4 * 512));
     bf16x8 r;
@@ -337,10 +364,19 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
     const int ns = 2 * nt;                         // 32-deep slabs
     const int64_t kb0 = (int64_t)kt0 * BK;
     const int grp = wm;                            // 0: leads, 1: one barrier behind
+    SlabPlan<A_KM> pa;
+    SlabPlan<B_KM> pb_;
+    pa.init(A, g.lda, m0, kb0, wave, lane);
+    pb_.init(B, g.ldb, n0, kb0, wave, lane);
+    uint32_t fa[8], fb[4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) fa[mi] = frag_off<A_KM>(wm * 8 + mi, lane);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) fb[ni] = frag_off<B_KM>(wn * 4 + ni, lane) + SLAB_BYTES;
     auto issue = [&](int j) {
       char* st = smem + (j & 3) * RING_STAGE;
-      stage_slab<A_KM>(st, A, g.lda, m0, kb0 + (int64_t)j * 32, wave, lane);
-      stage_slab<B_KM>(st + SLAB_BYTES, B, g.ldb, n0, kb0 + (int64_t)j * 32, wave, lane);
+      pa.issue(st, j, wave);
+      pb_.issue(st + SLAB_BYTES, j, wave);
     };
     issue(0);
     issue(1);
@@ -353,24 +389,27 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
       // ---- R(j)
       if (j + 3 < ns) issue(j + 3);
       const char* As = smem + (j & 3) * RING_STAGE;
-      const char* Bs = As + SLAB_BYTES;
       bf16x8 bf[4], af[8];
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) bf[ni] = slab_frag<B_KM>(Bs, wn * 4 + ni, lane);
+      for (int ni = 0; ni < 4; ++ni) bf[ni] = slab_frag<B_KM>(As, fb[ni]);
 #pragma unroll
-      for (int mi = 0; mi < 8; ++mi) af[mi] = slab_frag<A_KM>(As, wm * 8 + mi, lane);
+      for (int mi = 0; mi < 8; ++mi) af[mi] = slab_frag<A_KM>(As, fa[mi]);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of this stage are complete
       const int rem = ns - 2 - j;                   // slabs younger than j+1 already issued
       if (grp == 1) wait_vm(rem >= 2 ? 8 : (rem == 1 ? 4 : 0));
       raw_barrier();
       // ---- M(j)
+#ifdef VITMI_GEMM_SETPRIO
       __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
       for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+#ifdef VITMI_GEMM_SETPRIO
       __builtin_amdgcn_s_setprio(0);
+#endif
       if (grp == 0) wait_vm(rem >= 2 ? 8 : (rem == 1 ? 4 : 0));
       if (!(grp == 1 && j == ns - 1)) raw_barrier();
     }
