@@ -21,6 +21,7 @@ struct GemmArgs {
   const void* A; int64_t lda; int a_km;
   const void* B; int64_t ldb; int b_km;
   void* ws; size_t ws_bytes;      // optional scratch (split-K partial tiles)
+  unsigned long long* dbg;        // diagnostic phase stamps (NULL in production)
   EpiArgs e;
 };
 

@@ -11,6 +11,11 @@ bool gemm_fast_supported(const GemmArgs& g, int in_bf16);
 int gemm_fast_launch(const GemmArgs& g, hipStream_t stream);
 size_t gemm_fast_workspace(const GemmArgs& g);
 
+// diagnostic only (tools/gemm_phases.py): block 0 of the PIPE=1 kernel accumulates
+// s_memtime stamps of its R / M phases and barrier waits into this buffer
+static unsigned long long* g_gemm_dbg = nullptr;
+extern "C" void vitmi_debug_gemm_stamps(unsigned long long* buf) { g_gemm_dbg = buf; }
+
 namespace {
 
 constexpr int GBM = 64, GBN = 64, GBK = 32;
@@ -104,6 +109,7 @@ static int build_args(const vitmi_gemm_desc* d, GemmArgs* out) {
   g.A = d->A; g.lda = d->lda; g.a_km = d->a_kmajor ? 1 : 0;
   g.B = d->B; g.ldb = d->ldb; g.b_km = d->b_kmajor ? 1 : 0;
   g.ws = d->workspace; g.ws_bytes = d->workspace_bytes;
+  g.dbg = g_gemm_dbg;
   if (g.ws && !is_aligned(g.ws, 16)) { g.ws = nullptr; g.ws_bytes = 0; }
   EpiArgs& e = g.e;
   e.mode = d->epilogue;

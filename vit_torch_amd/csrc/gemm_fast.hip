@@ -146,25 +146,50 @@ __device__ __forceinline__ uint32_t frag_off(int rb, int lane) {
     return (uint32_t)(row * 512 + ((rb ^ key) * 32) + 8 * (i & 3));
   }
 }
-template <bool KM>
-__device__ __forceinline__ bf16x8 slab_frag(const char* slab, uint32_t off) {
-  if constexpr (KM) {
-    return *reinterpret_cast<const bf16x8*>(slab + off);
-  } else {
-    const char* p = slab + off;
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, p));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, p + 4 * 512));
-    bf16x8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return r;
+// A fragment in flight: for the k-major image one ds_read_b128 the compiler tracks; for
+// the k-row image two ds_read_b64_tr_b16 issued from INLINE ASM.  The builtin form makes
+// hipcc put `s_waitcnt vmcnt(0)` in front of every transposed read while an LDS-DMA is
+// outstanding (it cannot prove the read does not alias the DMA's LDS destination), which
+// drains the ring every slab; asm reads are invisible to that pass.  Their results are
+// only touched after frag_wait() names them (guide §5.7 item 1, form (ii)).
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <bool KM> struct Frag;
+template <> struct Frag<true> {
+  bf16x8 v;
+  __device__ __forceinline__ void load(const char* slab, uint32_t off) {
+    v = *reinterpret_cast<const bf16x8*>(slab + off);
   }
+  __device__ __forceinline__ bf16x8 get() const { return v; }
+};
+template <> struct Frag<false> {
+  u32x2 lo, hi;
+  __device__ __forceinline__ void load(const char* slab, uint32_t off) {
+    const uint32_t a = (uint32_t)(uintptr_t)LDS_PTR(char, slab) + off;
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:2048"
+                 : "=&v"(lo), "=&v"(hi) : "v"(a) : "memory");
+  }
+  __device__ __forceinline__ bf16x8 get() const {
+    const u32x4 r = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8, r);
+  }
+};
+__device__ __forceinline__ void frag_wait4(Frag<true>&, Frag<true>&, Frag<true>&, Frag<true>&) {}
+__device__ __forceinline__ void frag_wait4(Frag<false>& a, Frag<false>& b, Frag<false>& c, Frag<false>& d) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi), "+v"(c.lo), "+v"(c.hi), "+v"(d.lo), "+v"(d.hi)
+               :: "memory");
 }
 // all but the `n` youngest of this wave's vector-memory ops (LDS-DMA included) are done
 __device__ __forceinline__ void wait_vm(int n) {
   if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  return t;
 }
 __device__ __forceinline__ void raw_barrier() {
   __builtin_amdgcn_sched_barrier(0);
@@ -384,20 +409,34 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
     wait_vm(ns > 2 ? 8 : 4);                       // slab 0 has landed
     raw_barrier();                                 // b0
     if (grp == 1) raw_barrier();                   // stagger
+    const bool dbg = g.dbg != nullptr && blockIdx.x == 0;   // wave-uniform
+    unsigned long long tR = 0, tWR = 0, tM = 0, tWM = 0, t0 = 0, t1 = 0;
 #pragma unroll 1
     for (int j = 0; j < ns; ++j) {
+      if (dbg) t0 = stamp();
       // ---- R(j)
       if (j + 3 < ns) issue(j + 3);
       const char* As = smem + (j & 3) * RING_STAGE;
+      Frag<B_KM> fbv[4];
+      Frag<A_KM> fav[8];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) fbv[ni].load(As, fb[ni]);
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) fav[mi].load(As, fa[mi]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of this stage are complete
+      frag_wait4(fbv[0], fbv[1], fbv[2], fbv[3]);
+      frag_wait4(fav[0], fav[1], fav[2], fav[3]);
+      frag_wait4(fav[4], fav[5], fav[6], fav[7]);
       bf16x8 bf[4], af[8];
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) bf[ni] = slab_frag<B_KM>(As, fb[ni]);
+      for (int ni = 0; ni < 4; ++ni) bf[ni] = fbv[ni].get();
 #pragma unroll
-      for (int mi = 0; mi < 8; ++mi) af[mi] = slab_frag<A_KM>(As, fa[mi]);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of this stage are complete
+      for (int mi = 0; mi < 8; ++mi) af[mi] = fav[mi].get();
       const int rem = ns - 2 - j;                   // slabs younger than j+1 already issued
       if (grp == 1) wait_vm(rem >= 2 ? 8 : (rem == 1 ? 4 : 0));
+      if (dbg) { t1 = stamp(); tR += t1 - t0; }
       raw_barrier();
+      if (dbg) { t0 = stamp(); tWR += t0 - t1; }
       // ---- M(j)
 #ifdef VITMI_GEMM_SETPRIO
       __builtin_amdgcn_s_setprio(1);
@@ -411,7 +450,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
       __builtin_amdgcn_s_setprio(0);
 #endif
       if (grp == 0) wait_vm(rem >= 2 ? 8 : (rem == 1 ? 4 : 0));
+      if (dbg) { t1 = stamp(); tM += t1 - t0; }
       if (!(grp == 1 && j == ns - 1)) raw_barrier();
+      if (dbg) { t0 = stamp(); tWM += t0 - t1; }
+    }
+    if (dbg && lane == 0) {
+      g.dbg[wave * 4 + 0] = tR; g.dbg[wave * 4 + 1] = tWR;
+      g.dbg[wave * 4 + 2] = tM; g.dbg[wave * 4 + 3] = tWM;
+      g.dbg[32 + wave] = ns;
     }
   }
 
