@@ -321,13 +321,26 @@ def test_sgd_momentum_two_steps_match_torch(ops):
 
 
 # ------------------------------------------------------------- fast gemm ---
-FAST_SHAPES = [(256, 256, 64), (512, 768, 768), (768, 512, 1024), (1024, 256, 128)]
+FAST_SHAPES = [(256, 256, 64), (512, 768, 768), (768, 512, 1024), (1024, 256, 128), (256, 512, 192),
+               (512, 256, 6464)]
+
+
+@pytest.fixture(params=[0, 1, 2])
+def pipe(request, lib):
+    """Run a test once per main-loop variant of the fast GEMM (simple / 4-slab ring /
+    64-deep full-line stages), through the diagnostic hook the library exports."""
+    import ctypes
+    from vit_torch_amd import _lib as L
+    raw = ctypes.CDLL(str(L.LIB_PATH))
+    raw.vitmi_debug_gemm_pipe(request.param)
+    yield request.param
+    raw.vitmi_debug_gemm_pipe(-1)
 
 
 @pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
 @pytest.mark.parametrize("M,N,K", FAST_SHAPES)
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
-def test_gemm_fast_layouts(ops, layout, M, N, K, cdt):
+def test_gemm_fast_layouts(ops, pipe, layout, M, N, K, cdt):
     from vit_torch_amd._lib import GEMM_FAST
     akm, bkm = {"nt": (True, True), "nn": (True, False), "tn": (False, False)}[layout]
     a, b = bf16_round(gen((M, K), 1)), bf16_round(gen((N, K), 2))
@@ -339,7 +352,7 @@ def test_gemm_fast_layouts(ops, layout, M, N, K, cdt):
     assert_close(f"gemm_fast[{layout}]", C, want, 1e-4 if cdt == torch.float32 else TOL[cdt])
 
 
-def test_gemm_fast_epilogues(ops):
+def test_gemm_fast_epilogues(ops, pipe):
     from vit_torch_amd._lib import (EPI_BIAS_GELU, EPI_DGELU, EPI_PATCH_POS, EPI_RESIDUAL, GEMM_FAST)
     M, N, K = 512, 256, 192
     bt = torch.bfloat16
@@ -384,7 +397,7 @@ def test_gemm_fast_epilogues(ops):
         assert_close(f"patch_pos[{rdt}]", X, want, TOL[rdt] if rdt == bt else 1e-4)
 
 
-def test_gemm_fast_matches_generic_bitwise_on_integers(ops):
+def test_gemm_fast_matches_generic_bitwise_on_integers(ops, pipe):
     """Exact check of the fragment/tile index maps: small-integer operands make every
     product and partial sum exact in fp32, so fast and generic must agree bit for bit
     (asymmetric data, guide §3 'A=I-check with ASYMMETRIC B')."""

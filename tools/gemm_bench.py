@@ -50,5 +50,13 @@ def run(spec, iters=20):
 
 
 if __name__ == "__main__":
-    for s in (sys.argv[1:] or DEFAULT):
-        run(s)
+    import ctypes
+    from vit_torch_amd import _lib
+    raw = ctypes.CDLL(str(_lib.LIB_PATH))
+    specs = [a for a in sys.argv[1:] if not a.startswith("pipe=")]
+    pipes = [int(a[5:]) for a in sys.argv[1:] if a.startswith("pipe=")] or [-1]
+    for pm in pipes:
+        raw.vitmi_debug_gemm_pipe(pm)
+        print(f"--- pipe {pm}")
+        for s in (specs or DEFAULT):
+            run(s)

@@ -10,6 +10,7 @@ lib = _lib.load()
 raw = ctypes.CDLL(str(_lib.LIB_PATH))
 raw.vitmi_debug_gemm_stamps.argtypes = [ctypes.c_void_p]
 buf = torch.zeros(64, dtype=torch.int64, device="cuda")
+raw.vitmi_debug_gemm_pipe(int(os.environ.get("PIPE", "-1")))
 for spec in (sys.argv[1:] or ["nt:8192:8192:8192", "tn:4096:4096:4096", "nt:50432:2304:768", "nn:50432:768:3072"]):
     layout, M, N, K = spec.split(":")[0], *map(int, spec.split(":")[1:4])
     akm, bkm = {"nt": (True, True), "nn": (True, False), "tn": (False, False)}[layout]

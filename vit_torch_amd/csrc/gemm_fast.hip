@@ -180,6 +180,65 @@ __device__ __forceinline__ void frag_wait4(Frag<false>& a, Frag<false>& b, Frag<
                : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi), "+v"(c.lo), "+v"(c.hi), "+v"(d.lo), "+v"(d.hi)
                :: "memory");
 }
+// ---- PIPE=2 building blocks: 64-deep stages whose k-major image is filled with FULL
+// 128-B lines.  With 32-deep slabs a k-major operand is fetched as 64-B row pieces (16
+// half lines per LDS-DMA instruction, every line touched twice, a slab apart): the
+// texture-address path, not the MFMA, then paces the R phase (measured: R 750 cycles
+// for NT against 620 for TN at 8192^3).  Here one instruction moves 8 rows x 128 B.
+// Row image: [256 rows][128 B], 16-B chunk c of row r stored at chunk c ^ ((r>>1)&7)
+// (conflict-free for the ds_read_b128 lane groups: within a group the 16 rows at chunk
+// c / c+1 land on 16 distinct 16-B slots).
+template <bool KM> struct StagePlan {
+  const char* base[4];     // wave-uniform
+  uint32_t off[4];         // per lane
+  int64_t step;            // bytes per 64-deep stage
+  __device__ __forceinline__ void init(const bf16* X, int64_t ld, int64_t r0, int64_t k0, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int st = wave * 4 + i;
+      if constexpr (KM) {  // 32 subtiles of 8 rows x 64 k
+        const int row = st * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        base[i] = reinterpret_cast<const char*>(X + (r0 + st * 8) * ld + k0);
+        off[i] = (uint32_t)(((lane >> 3) * ld + c * 8) * 2);
+      } else {             // 32 pairs of 512-B k-rows
+        const int row = 2 * st + (lane >> 5);
+        const int pc16 = lane & 31;
+        const int key = (row & 3) | (((row >> 3) & 1) << 2);
+        const int c32 = (pc16 >> 1) ^ key;
+        base[i] = reinterpret_cast<const char*>(X + (k0 + 2 * st) * ld + r0);
+        off[i] = (uint32_t)(((lane >> 5) * ld + c32 * 16 + (pc16 & 1) * 8) * 2);
+      }
+    }
+    step = KM ? 128 : 128 * ld;
+  }
+  __device__ __forceinline__ void issue(char* tile, int t, int wave) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      glds16(base[i] + (int64_t)t * step + off[i], tile + (wave * 4 + i) * 1024);
+  }
+};
+// per-lane LDS byte offset (k-half 0) of the fragment of block rb in a 64-deep stage
+// image; k-half 1 is `off ^ 64` (k-major) / `off + 16384` (k-rows)
+template <bool KM>
+__device__ __forceinline__ uint32_t frag_off64(int rb, int lane) {
+  if constexpr (KM) {
+    const int row = rb * 16 + (lane & 15);
+    const int pc = (lane >> 4) ^ ((row >> 1) & 7);
+    return (uint32_t)(row * 128 + pc * 16);
+  } else {
+    const int g = lane >> 4, i = lane & 15;
+    const int row = 8 * g + (i >> 2);
+    const int key = (row & 3) | (((row >> 3) & 1) << 2);
+    return (uint32_t)(row * 512 + ((rb ^ key) * 32) + 8 * (i & 3));
+  }
+}
+template <bool KM>
+__device__ __forceinline__ uint32_t frag_half(uint32_t off, int kh) {
+  if constexpr (KM) return kh ? (off ^ 64u) : off;
+  else return off + (uint32_t)kh * 16384u;
+}
+
 // all but the `n` youngest of this wave's vector-memory ops (LDS-DMA included) are done
 __device__ __forceinline__ void wait_vm(int n) {
   if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -385,7 +444,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
     __syncthreads();   // next stage landed (vmcnt(0)) and everyone is done reading `cur`
   }
 
-  } else {
+  } else if constexpr (PIPE == 1) {
     const int ns = 2 * nt;                         // 32-deep slabs
     const int64_t kb0 = (int64_t)kt0 * BK;
     const int grp = wm;                            // 0: leads, 1: one barrier behind
@@ -450,6 +509,75 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
       __builtin_amdgcn_s_setprio(0);
 #endif
       if (grp == 0) wait_vm(rem >= 2 ? 8 : (rem == 1 ? 4 : 0));
+      if (dbg) { t1 = stamp(); tM += t1 - t0; }
+      if (!(grp == 1 && j == ns - 1)) raw_barrier();
+      if (dbg) { t0 = stamp(); tWM += t0 - t1; }
+    }
+    if (dbg && lane == 0) {
+      g.dbg[wave * 4 + 0] = tR; g.dbg[wave * 4 + 1] = tWR;
+      g.dbg[wave * 4 + 2] = tM; g.dbg[wave * 4 + 3] = tWM;
+      g.dbg[32 + wave] = ns;
+    }
+  } else {
+    // PIPE == 2: two 64-deep stages (full-line LDS-DMA), the same two wave groups one
+    // barrier apart; stage t+1 is issued at R(2t) into the buffer stage t-1 has just
+    // vacated and waited for (vmcnt(0)) at the end of phase 2t+1.
+    const int ns = 2 * nt;
+    const int64_t kb0 = (int64_t)kt0 * BK;
+    const int grp = wm;
+    StagePlan<A_KM> pa;
+    StagePlan<B_KM> pb_;
+    pa.init(A, g.lda, m0, kb0, wave, lane);
+    pb_.init(B, g.ldb, n0, kb0, wave, lane);
+    uint32_t fa[8], fb[4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) fa[mi] = frag_off64<A_KM>(wm * 8 + mi, lane);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) fb[ni] = frag_off64<B_KM>(wn * 4 + ni, lane);
+    auto issue = [&](int t) {
+      char* st = smem + (t & 1) * STAGE_BYTES;
+      pa.issue(st, t, wave);
+      pb_.issue(st + TILE_BYTES, t, wave);
+    };
+    issue(0);
+    if (nt > 1) issue(1);
+    wait_vm(nt > 1 ? 8 : 0);
+    raw_barrier();
+    if (grp == 1) raw_barrier();
+    const bool dbg = g.dbg != nullptr && blockIdx.x == 0;
+    unsigned long long tR = 0, tWR = 0, tM = 0, tWM = 0, t0 = 0, t1 = 0;
+#pragma unroll 1
+    for (int j = 0; j < ns; ++j) {
+      if (dbg) t0 = stamp();
+      const int t = j >> 1, kh = j & 1;
+      if (kh == 0 && t >= 1 && t + 1 < nt) issue(t + 1);
+      const char* At = smem + (t & 1) * STAGE_BYTES;
+      const char* Bt = At + TILE_BYTES;
+      Frag<B_KM> fbv[4];
+      Frag<A_KM> fav[8];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) fbv[ni].load(Bt, frag_half<B_KM>(fb[ni], kh));
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) fav[mi].load(At, frag_half<A_KM>(fa[mi], kh));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      frag_wait4(fbv[0], fbv[1], fbv[2], fbv[3]);
+      frag_wait4(fav[0], fav[1], fav[2], fav[3]);
+      frag_wait4(fav[4], fav[5], fav[6], fav[7]);
+      bf16x8 bf[4], af[8];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) bf[ni] = fbv[ni].get();
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) af[mi] = fav[mi].get();
+      if (grp == 1 && kh == 1) wait_vm(0);
+      if (dbg) { t1 = stamp(); tR += t1 - t0; }
+      raw_barrier();
+      if (dbg) { t0 = stamp(); tWR += t0 - t1; }
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+      if (grp == 0 && kh == 1) wait_vm(0);
       if (dbg) { t1 = stamp(); tM += t1 - t0; }
       if (!(grp == 1 && j == ns - 1)) raw_barrier();
       if (dbg) { t0 = stamp(); tWM += t0 - t1; }
@@ -537,11 +665,16 @@ inline void splitk_plan(int tiles, int nt, int* splits, int* ksps) {
   *splits = (nt + k - 1) / k;
 }
 
-static int pipe_mode() {
-  static int mode = -1;
-  if (mode < 0) {
+static int g_pipe_override = -1;
+// diagnostic / test hook: force the main-loop variant (0, 1, 2) or -1 = automatic
+extern "C" void vitmi_debug_gemm_pipe(int mode) { g_pipe_override = mode; }
+
+static int pipe_mode() {   // -1 = automatic (per layout), else forced 0/1/2
+  if (g_pipe_override >= 0) return g_pipe_override;
+  static int mode = -2;
+  if (mode == -2) {
     const char* e = getenv("VITMI_GEMM_PIPE");
-    mode = (e && e[0] == '0') ? 0 : 1;
+    mode = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : -1;
   }
   return mode;
 }
@@ -551,7 +684,11 @@ int launch_p(const GemmArgs& g, hipStream_t stream);
 
 template <bool A_KM, bool B_KM, int MODE, typename TC>
 int launch(const GemmArgs& g, hipStream_t stream) {
-  return pipe_mode() ? launch_p<A_KM, B_KM, MODE, TC, 1>(g, stream) : launch_p<A_KM, B_KM, MODE, TC, 0>(g, stream);
+  int pm = pipe_mode();
+  if (pm < 0) pm = (A_KM && B_KM) ? 2 : 1;   // k-major operands want full-line DMA (PIPE 2)
+  if (pm == 0) return launch_p<A_KM, B_KM, MODE, TC, 0>(g, stream);
+  if (pm == 1) return launch_p<A_KM, B_KM, MODE, TC, 1>(g, stream);
+  return launch_p<A_KM, B_KM, MODE, TC, 2>(g, stream);
 }
 
 template <bool A_KM, bool B_KM, int MODE, typename TC, int PIPE>
