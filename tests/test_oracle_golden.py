@@ -1,0 +1,96 @@
+"""The oracle (oracle/vit_ref.py) against golden vectors produced by the REFERENCE's own
+classes (tests/golden/gen_golden.py imports /root/reference/models/{cait,swin}.py).
+CPU only.  Tolerance 2e-6 relative to max|ref| (fp32, same op order)."""
+import os
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from util import assert_close
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    top, groups = {}, {}
+    for k in z.files:
+        if "/" in k:
+            g, kk = k.split("/", 1)
+            groups.setdefault(g, {})[kk] = torch.from_numpy(z[k])
+        else:
+            top[k] = torch.from_numpy(z[k])
+    return top, groups
+
+
+def check_module(mod, top, groups, tol=2e-6):
+    missing = mod.load_state_dict(groups["state"], strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    x = top["x"].clone().requires_grad_(True)
+    y = mod(x)
+    assert_close("y", y, top["y"], tol)
+    y.backward(top["dy"])
+    assert_close("dx", x.grad, top["dx"], tol * 5)
+    for n, p in mod.named_parameters():
+        assert_close(f"grad[{n}]", p.grad, groups["grad"][n], tol * 5)
+
+
+@pytest.mark.parametrize("scale_before", [True, False])
+def test_block_matches_reference_layerscale_block(scale_before):
+    """cait.LayerScale_Block with gamma = 1 and identity talking-heads mixes == oracle Block.
+    scale_before=False is the DINO order ([recall]): same maths, different rounding."""
+    from oracle.vit_ref import Block
+    top, groups = load("vit_block")
+    blk = Block(64, 2, 4.0, True, partial(nn.LayerNorm, eps=1e-6), scale_before=scale_before)
+    check_module(blk, top, groups, 2e-6 if scale_before else 1e-5)
+
+
+def test_mlp_matches_reference_swin_mlp():
+    from oracle.vit_ref import Mlp
+    top, groups = load("mlp")
+    check_module(Mlp(48, 96), top, groups)
+
+
+def test_attention_matches_reference_window_attention_without_bias():
+    from oracle.vit_ref import Attention
+    top, groups = load("mhsa_from_window_attention")
+    check_module(Attention(32, num_heads=2, qkv_bias=True, scale_before=True), top, groups)
+
+
+def test_classifier_head_shape_contract():
+    """get_classifier_head (models/vision_all.py:299-320): hidden Linear(bias) + shared act, last Linear(bias=False)."""
+    from oracle.vit_ref import get_classifier_head
+    h = get_classifier_head(384, [49, 31, 7])
+    mods = list(h)
+    assert [type(m).__name__ for m in mods] == ["Linear", "GELU", "Linear", "GELU", "Linear"]
+    assert mods[1] is mods[3]
+    assert mods[0].bias is not None and mods[2].bias is not None and mods[4].bias is None
+    assert list(get_classifier_head(768, 10))[0].bias is None
+
+
+def test_product_factory_mirrors_reference_head_contract():
+    from vit_torch_amd import VisionModelZoo
+    h = VisionModelZoo.get_classifier_head(384, [49, 31, 7])
+    mods = list(h)
+    assert [type(m).__name__ for m in mods] == ["Linear", "GELU", "Linear", "GELU", "Linear"]
+    assert mods[4].bias is None and mods[1] is mods[3]
+    with pytest.raises(ValueError):
+        VisionModelZoo.get_model("no_such_arch", pretrained=False)
+    m = VisionModelZoo.get_model("dino_vits16", pretrained=False, classifier=[24, 10])
+    assert isinstance(m.patch_embed.proj, nn.Conv2d) and m.norm.weight.shape[-1] == 384
+    assert isinstance(m.head, nn.Sequential) and m.apply_head
+    back, head = VisionModelZoo.get_model("dino_vits16", pretrained=False, classifier=10, return_separate=True)
+    assert isinstance(back.head, nn.Identity) and isinstance(head, nn.Sequential)
+
+
+def test_state_dict_names_match_oracle():
+    from oracle import vit_ref
+    from vit_torch_amd import VisionModelZoo
+    ref = vit_ref.build("dino_vits16", classifier=10)
+    m = VisionModelZoo.get_model("dino_vits16", pretrained=False, classifier=10)
+    assert list(ref.state_dict().keys()) == list(m.state_dict().keys())
+    for (k, a), (_, b) in zip(ref.state_dict().items(), m.state_dict().items()):
+        assert a.shape == b.shape, k
