@@ -322,19 +322,25 @@ def test_sgd_momentum_two_steps_match_torch(ops):
 
 # ------------------------------------------------------------- fast gemm ---
 FAST_SHAPES = [(256, 256, 64), (512, 768, 768), (768, 512, 1024), (1024, 256, 128), (256, 512, 192),
-               (512, 256, 6464)]
+               (512, 256, 6464), (256, 128, 64), (512, 384, 320)]
 
 
-@pytest.fixture(params=[0, 1, 2])
+@pytest.fixture(params=["t1p0", "t1p1", "t1p2", "t2"])
 def pipe(request, lib):
-    """Run a test once per main-loop variant of the fast GEMM (simple / 4-slab ring /
-    64-deep full-line stages), through the diagnostic hook the library exports."""
+    """Run a test once per variant of the fast GEMM — 256x256 tiles with the simple /
+    4-slab-ring / 64-deep-stage main loops, and 256x128 tiles with two workgroups per CU —
+    through the diagnostic hooks the library exports."""
     import ctypes
     from vit_torch_amd import _lib as L
     raw = ctypes.CDLL(str(L.LIB_PATH))
-    raw.vitmi_debug_gemm_pipe(request.param)
+    if request.param == "t2":
+        raw.vitmi_debug_gemm_tile(2)
+    else:
+        raw.vitmi_debug_gemm_tile(1)
+        raw.vitmi_debug_gemm_pipe(int(request.param[-1]))
     yield request.param
     raw.vitmi_debug_gemm_pipe(-1)
+    raw.vitmi_debug_gemm_tile(-1)
 
 
 @pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
@@ -342,6 +348,8 @@ def pipe(request, lib):
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
 def test_gemm_fast_layouts(ops, pipe, layout, M, N, K, cdt):
     from vit_torch_amd._lib import GEMM_FAST
+    if N % 256 and pipe != "t2":
+        pytest.skip("256x256 tiles need N % 256 == 0")
     akm, bkm = {"nt": (True, True), "nn": (True, False), "tn": (False, False)}[layout]
     a, b = bf16_round(gen((M, K), 1)), bf16_round(gen((N, K), 2))
     want = a @ b.t()

@@ -54,9 +54,12 @@ if __name__ == "__main__":
     from vit_torch_amd import _lib
     raw = ctypes.CDLL(str(_lib.LIB_PATH))
     specs = [a for a in sys.argv[1:] if not a.startswith("pipe=")]
+    specs = [a for a in specs if not a.startswith("tile=")]
     pipes = [int(a[5:]) for a in sys.argv[1:] if a.startswith("pipe=")] or [-1]
-    for pm in pipes:
+    tiles = [int(a[5:]) for a in sys.argv[1:] if a.startswith("tile=")] or [-1]
+    for tm, pm in [(t, p) for t in tiles for p in pipes]:
+        raw.vitmi_debug_gemm_tile(tm)
         raw.vitmi_debug_gemm_pipe(pm)
-        print(f"--- pipe {pm}")
+        print(f"--- tile {tm} pipe {pm}")
         for s in (specs or DEFAULT):
             run(s)

@@ -24,12 +24,13 @@ SOURCES = [
     "core.cpp",
     "gemm.hip",
     "gemm_fast.hip",
+    "gemm_fast2.hip",
     "layernorm.hip",
     "elementwise.hip",
     "attention.hip",
     "attention_f32.hip",
 ]
-HEADERS = ["common.h", "epilogue.h", "../../include/vitmi.h"]
+HEADERS = ["common.h", "epilogue.h", "gemm_tile.h", "../../include/vitmi.h"]
 
 FLAGS = [
     f"--offload-arch={ARCH}",

@@ -22,8 +22,7 @@
 // Block -> tile map is XCD-aware (8 XCDs, private L2s): each XCD walks a
 // contiguous run of tiles, n fastest, so the A panel of a row of tiles and the
 // whole weight matrix stay in that XCD's L2.
-#include <cstdlib>
-#include "epilogue.h"
+#include "gemm_tile.h"
 
 namespace {
 
@@ -31,11 +30,6 @@ constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int TILE_BYTES = 256 * 64 * 2;       // one operand tile: 32 KiB
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + B
 constexpr int NTHREADS = 512;
-
-__device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
-}
 
 // ---- staging: each wave issues 4 LDS-DMA instructions (1 KiB each) per tile
 template <bool KM>
@@ -146,40 +140,6 @@ __device__ __forceinline__ uint32_t frag_off(int rb, int lane) {
     return (uint32_t)(row * 512 + ((rb ^ key) * 32) + 8 * (i & 3));
   }
 }
-// A fragment in flight: for the k-major image one ds_read_b128 the compiler tracks; for
-// the k-row image two ds_read_b64_tr_b16 issued from INLINE ASM.  The builtin form makes
-// hipcc put `s_waitcnt vmcnt(0)` in front of every transposed read while an LDS-DMA is
-// outstanding (it cannot prove the read does not alias the DMA's LDS destination), which
-// drains the ring every slab; asm reads are invisible to that pass.  Their results are
-// only touched after frag_wait() names them (guide §5.7 item 1, form (ii)).
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-template <bool KM> struct Frag;
-template <> struct Frag<true> {
-  bf16x8 v;
-  __device__ __forceinline__ void load(const char* slab, uint32_t off) {
-    v = *reinterpret_cast<const bf16x8*>(slab + off);
-  }
-  __device__ __forceinline__ bf16x8 get() const { return v; }
-};
-template <> struct Frag<false> {
-  u32x2 lo, hi;
-  __device__ __forceinline__ void load(const char* slab, uint32_t off) {
-    const uint32_t a = (uint32_t)(uintptr_t)LDS_PTR(char, slab) + off;
-    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:2048"
-                 : "=&v"(lo), "=&v"(hi) : "v"(a) : "memory");
-  }
-  __device__ __forceinline__ bf16x8 get() const {
-    const u32x4 r = {lo[0], lo[1], hi[0], hi[1]};
-    return __builtin_bit_cast(bf16x8, r);
-  }
-};
-__device__ __forceinline__ void frag_wait4(Frag<true>&, Frag<true>&, Frag<true>&, Frag<true>&) {}
-__device__ __forceinline__ void frag_wait4(Frag<false>& a, Frag<false>& b, Frag<false>& c, Frag<false>& d) {
-  asm volatile("s_waitcnt lgkmcnt(0)"
-               : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi), "+v"(c.lo), "+v"(c.hi), "+v"(d.lo), "+v"(d.hi)
-               :: "memory");
-}
 // ---- PIPE=2 building blocks: 64-deep stages whose k-major image is filled with FULL
 // 128-B lines.  With 32-deep slabs a k-major operand is fetched as 64-B row pieces (16
 // half lines per LDS-DMA instruction, every line touched twice, a slab apart): the
@@ -239,133 +199,6 @@ __device__ __forceinline__ uint32_t frag_half(uint32_t off, int kh) {
   else return off + (uint32_t)kh * 16384u;
 }
 
-// all but the `n` youngest of this wave's vector-memory ops (LDS-DMA included) are done
-__device__ __forceinline__ void wait_vm(int n) {
-  if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-__device__ __forceinline__ unsigned long long stamp() {
-  unsigned long long t;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
-  return t;
-}
-__device__ __forceinline__ void raw_barrier() {
-  __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-}
-
-// ---- fast GELU for the bf16 epilogues: erf by Abramowitz-Stegun 7.1.26
-// (|abs err| <= 1.5e-7, far below bf16 resolution); ONE exp serves both the erf
-// tail and the Gaussian pdf, so gelu' costs no second transcendental.  The fp32
-// parity mode (generic kernel) keeps erff.
-__device__ __forceinline__ void gelu_parts(float x, float* cdf, float* pdf) {
-  const float ax = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * ax);
-  const float ex = __expf(-ax * ax);                      // exp(-x^2/2)
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f +
-                     t * (-1.453152027f + t * 1.061405429f))));
-  const float erf_abs = 1.f - poly * ex;
-  *cdf = 0.5f * (1.f + copysignf(erf_abs, x));
-  *pdf = 0.39894228040143267794f * ex;
-}
-
-// ---- W-wide row vectors (W = 8 for bf16 outputs = 16 B, W = 4 for fp32 = 16 B)
-template <typename T, int W>
-__device__ __forceinline__ void loadv(const T* p, float (&o)[W]) {
-  if constexpr (sizeof(T) == 2 && W == 8) {
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
-  } else {
-#pragma unroll
-    for (int q = 0; q < W / 4; ++q) {
-      const f32x4 v = load4<T>(p + 4 * q);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) o[4 * q + i] = v[i];
-    }
-  }
-}
-template <typename T, int W>
-__device__ __forceinline__ void storev(T* p, const float (&v)[W]) {
-  if constexpr (sizeof(T) == 2 && W == 8) {
-    bf16x8 o;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = (bf16)v[i];
-    *reinterpret_cast<bf16x8*>(p) = o;
-  } else {
-#pragma unroll
-    for (int q = 0; q < W / 4; ++q) {
-      const f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-      store4<T>(p + 4 * q, o);
-    }
-  }
-}
-
-// epilogue on W consecutive columns n.. of row m; v = raw accumulators in, stored out
-// b / gm: bias and LayerScale of the lane's W columns (the same for every row, so the
-// caller loads them ONCE: a load inside the row loop would put a vmcnt wait, which also
-// counts the previous rows' stores, in front of every store)
-template <int MODE, typename TC, int W>
-__device__ __forceinline__ void epi_row(const EpiArgs& e, int64_t m, int64_t n, float (&v)[W],
-                                        const float (&b)[W], const float (&gm)[W]) {
-  TC* C = reinterpret_cast<TC*>(e.C);
-  if constexpr (MODE == VITMI_EPI_STORE) {
-#pragma unroll
-    for (int i = 0; i < W; ++i) v[i] = v[i] * e.alpha + b[i];
-    if constexpr (sizeof(TC) == 4) {
-      if (e.accumulate) {
-        float c[W];
-        loadv<float, W>(reinterpret_cast<const float*>(e.C) + m * e.ldc + n, c);
-#pragma unroll
-        for (int i = 0; i < W; ++i) v[i] += c[i];
-      }
-    }
-  } else if constexpr (MODE == VITMI_EPI_BIAS_GELU) {
-    float pre[W];
-#pragma unroll
-    for (int i = 0; i < W; ++i) {
-      pre[i] = v[i] + b[i];
-      if constexpr (sizeof(TC) == 2) pre[i] = (float)(bf16)pre[i];
-      float cdf, pdf;
-      gelu_parts(pre[i], &cdf, &pdf);
-      v[i] = pre[i] * cdf;
-    }
-    if (e.C2) storev<TC, W>(reinterpret_cast<TC*>(e.C2) + m * e.ldc2 + n, pre);
-  } else if constexpr (MODE == VITMI_EPI_RESIDUAL) {
-    float r[W];
-    loadv<TC, W>(reinterpret_cast<const TC*>(e.R) + m * e.ldr + n, r);
-#pragma unroll
-    for (int i = 0; i < W; ++i) v[i] = r[i] + gm[i] * (v[i] + b[i]);
-  } else if constexpr (MODE == VITMI_EPI_DGELU) {
-    float a[W];
-    loadv<bf16, W>(reinterpret_cast<const bf16*>(e.AUX) + m * e.ldaux + n, a);
-#pragma unroll
-    for (int i = 0; i < W; ++i) {
-      float cdf, pdf;
-      gelu_parts(a[i], &cdf, &pdf);
-      v[i] *= cdf + a[i] * pdf;
-    }
-  } else {  // PATCH_POS
-    const int64_t t = m % e.n_tok;
-    float ps[W];
-    loadv<float, W>(e.pos + t * e.ldpos + n, ps);
-    if (t == 0 && e.cls) {
-      float c[W];
-      loadv<float, W>(e.cls + n, c);
-#pragma unroll
-      for (int i = 0; i < W; ++i) v[i] = c[i] + ps[i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < W; ++i) v[i] = v[i] + b[i] + ps[i];
-    }
-  }
-  storev<TC, W>(C + m * e.ldc + n, v);
-}
-
-constexpr int TRS = 68;                       // floats per row of the transpose strip (64 + pad)
-constexpr int TR_BYTES = 16 * TRS * 4;        // one wave's 16-row strip
 
 // SPLITK: the grid is (tiles x splits); block (tile, s) contracts k-steps
 // [s*ksps, min((s+1)*ksps, nt)) and stores its raw fp32 partial tile into slab s
@@ -732,6 +565,24 @@ enum { OUT_BF16 = 0, OUT_F32 = 1 };
 
 }  // namespace
 
+bool gemm_fast2_shape_ok(const GemmArgs& g);
+size_t gemm_fast2_workspace(const GemmArgs& g);
+int gemm_fast2_launch(const GemmArgs& g, hipStream_t s);
+
+static int g_tile_override = -1;
+// diagnostic / test hook: 1 = 256x256 tiles (one 8-wave workgroup per CU),
+// 2 = 256x128 tiles (two 4-wave workgroups per CU), -1 = default
+extern "C" void vitmi_debug_gemm_tile(int mode) { g_tile_override = mode; }
+static int tile_mode() {
+  if (g_tile_override > 0) return g_tile_override;
+  static int mode = -2;
+  if (mode == -2) {
+    const char* e = getenv("VITMI_GEMM_TILE");
+    mode = (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 2;
+  }
+  return mode;
+}
+
 // which (layout, epilogue, output dtype) combinations are instantiated
 static bool combo_built(const GemmArgs& g) {
   const EpiArgs& e = g.e;
@@ -748,7 +599,8 @@ static bool combo_built(const GemmArgs& g) {
 
 bool gemm_fast_supported(const GemmArgs& g, int in_bf16) {
   if (!in_bf16) return false;
-  if (g.M % BM || g.N % BN || g.K % BK) return false;
+  const bool t2 = tile_mode() == 2 && gemm_fast2_shape_ok(g);
+  if (!t2 && (g.M % BM || g.N % BN || g.K % BK)) return false;
   if (g.M / BM * (g.N / BN) > (1 << 30)) return false;
   if (!combo_built(g)) return false;
   const EpiArgs& e = g.e;
@@ -766,6 +618,7 @@ bool gemm_fast_supported(const GemmArgs& g, int in_bf16) {
 }
 
 size_t gemm_fast_workspace(const GemmArgs& g) {
+  if (tile_mode() == 2 && gemm_fast2_shape_ok(g)) return gemm_fast2_workspace(g);
   if (g.e.mode != VITMI_EPI_STORE || g.e.c_bf16) return 0;
   int splits, ksps;
   splitk_plan((int)(g.M / BM * (g.N / BN)), (int)(g.K / BK), &splits, &ksps);
@@ -773,6 +626,7 @@ size_t gemm_fast_workspace(const GemmArgs& g) {
 }
 
 int gemm_fast_launch(const GemmArgs& g, hipStream_t s) {
+  if (tile_mode() == 2 && gemm_fast2_shape_ok(g)) return gemm_fast2_launch(g, s);
   const EpiArgs& e = g.e;
   const bool nt = g.a_km && g.b_km, nn = g.a_km && !g.b_km;
 #define GO(AKM, BKM, MODE) (e.c_bf16 ? launch<AKM, BKM, MODE, bf16>(g, s) : launch<AKM, BKM, MODE, float>(g, s))
