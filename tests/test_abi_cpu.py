@@ -77,4 +77,5 @@ def test_hot_shapes_take_the_fast_gemm(lib):
     assert ops.gemm_uses_fast(D, 4 * D, M, a_kmajor=False, b_kmajor=False, c_dtype=F32)   # fc2 wgrad
     # ragged shapes and fp32 operands go to the generic kernel
     assert not ops.gemm_uses_fast(256, 10, D, in_dtype=F32, c_dtype=F32)
-    assert not ops.gemm_uses_fast(640, 384, 384)
+    assert not ops.gemm_uses_fast(640, 384, 384)          # M not a multiple of 256
+    assert ops.gemm_uses_fast(256 * 5, 1152, 384)         # ViT-S qkv: N % 128 == 0 -> 256x128 tiles

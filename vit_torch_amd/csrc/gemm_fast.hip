@@ -578,9 +578,15 @@ static int tile_mode() {
   static int mode = -2;
   if (mode == -2) {
     const char* e = getenv("VITMI_GEMM_TILE");
-    mode = (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 2;
+    mode = (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 1;
   }
   return mode;
+}
+// 256x128 tiles are used when forced, or when N is a multiple of 128 but not of 256
+// (D = 384 models); measured equal-or-slower than 256x256 on the ViT-B shapes
+static bool use_tile2(const GemmArgs& g) {
+  if (!gemm_fast2_shape_ok(g)) return false;
+  return tile_mode() == 2 || (g.N % BN) != 0;
 }
 
 // which (layout, epilogue, output dtype) combinations are instantiated
@@ -599,8 +605,7 @@ static bool combo_built(const GemmArgs& g) {
 
 bool gemm_fast_supported(const GemmArgs& g, int in_bf16) {
   if (!in_bf16) return false;
-  const bool t2 = tile_mode() == 2 && gemm_fast2_shape_ok(g);
-  if (!t2 && (g.M % BM || g.N % BN || g.K % BK)) return false;
+  if (!use_tile2(g) && (g.M % BM || g.N % BN || g.K % BK)) return false;
   if (g.M / BM * (g.N / BN) > (1 << 30)) return false;
   if (!combo_built(g)) return false;
   const EpiArgs& e = g.e;
@@ -618,7 +623,7 @@ bool gemm_fast_supported(const GemmArgs& g, int in_bf16) {
 }
 
 size_t gemm_fast_workspace(const GemmArgs& g) {
-  if (tile_mode() == 2 && gemm_fast2_shape_ok(g)) return gemm_fast2_workspace(g);
+  if (use_tile2(g)) return gemm_fast2_workspace(g);
   if (g.e.mode != VITMI_EPI_STORE || g.e.c_bf16) return 0;
   int splits, ksps;
   splitk_plan((int)(g.M / BM * (g.N / BN)), (int)(g.K / BK), &splits, &ksps);
@@ -626,7 +631,7 @@ size_t gemm_fast_workspace(const GemmArgs& g) {
 }
 
 int gemm_fast_launch(const GemmArgs& g, hipStream_t s) {
-  if (tile_mode() == 2 && gemm_fast2_shape_ok(g)) return gemm_fast2_launch(g, s);
+  if (use_tile2(g)) return gemm_fast2_launch(g, s);
   const EpiArgs& e = g.e;
   const bool nt = g.a_km && g.b_km, nn = g.a_km && !g.b_km;
 #define GO(AKM, BKM, MODE) (e.c_bf16 ? launch<AKM, BKM, MODE, bf16>(g, s) : launch<AKM, BKM, MODE, float>(g, s))
