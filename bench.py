@@ -154,9 +154,19 @@ def main():
         tot_t = sum(r[2] for r in rows.values())
         n_launch = sum(r[0] for r in rows.values())
         ach = tot_f / tot_t / 1e12
+        # HBM bytes per launch of the same kernel from the committed rocprofv3 --pmc passes
+        # (FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_traffic.py); bench.py cannot collect PMCs itself
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            traffic = pm["gemm_fast_kernel"]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         roof = {"bound": "mfma", "kernel": "gemm_fast_kernel (all GEMM launches of one step)",
                 "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                "traffic_note": "bytes/launch, rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE of this command (profiles/r01_pmc_traffic.json)",
+                "flop_per_launch": round(tot_f / n_launch),
                 "launches_per_step": n_launch, "avg_launch_ms": round(tot_t / n_launch * 1e3, 4),
                 "gemm_ms_per_step": round(tot_t * 1e3, 3),
                 "by_shape": [{"kernel": k[0], "MNK": list(k[1]), "launches": v[0],
