@@ -114,13 +114,15 @@ int vitmi_layernorm_fwd(const void* x, int x_dtype, int64_t x_stride,
 
 size_t vitmi_layernorm_bwd_workspace(int64_t M, int64_t D);
 /* g_out = (g_in ? g_in : 0) + dLN/dx ; gb_out (optional) = cast(g_out);
- * dgamma/dbeta overwritten (fp32 [D]).  g_in may alias g_out. */
+ * dgamma/dbeta overwritten (fp32 [D]); gsum (optional, fp32 [D]) = column sum of g_out
+ * over the M rows = the bias gradient of the Linear whose output feeds this residual
+ * position (fused here to save a pass over g_out).  g_in may alias g_out. */
 int vitmi_layernorm_bwd(const void* dy, int dy_dtype, int64_t dy_stride,
                         const void* x, int x_dtype, int64_t x_stride,
                         const float* mean, const float* rstd, const float* gamma,
                         const void* g_in, void* g_out, int g_dtype, int64_t g_stride,
                         void* gb_out, int gb_dtype, int64_t gb_stride,
-                        float* dgamma, float* dbeta,
+                        float* dgamma, float* dbeta, float* gsum,
                         int64_t M, int64_t D,
                         void* workspace, size_t workspace_bytes, void* stream);
 

@@ -164,8 +164,10 @@ def test_layernorm_bwd(ops, M, D, T, R):
     Gb = torch.empty((M, D), device="cuda", dtype=T) if T != R else None
     dg = torch.empty(D, device="cuda")
     db = torch.empty(D, device="cuda")
-    ops.layernorm_bwd(dev(dy, T), dev(x, R), dev(mean), dev(rstd), dev(g), G, G, Gb, dg, db)
+    gsum = torch.empty(D, device="cuda")
+    ops.layernorm_bwd(dev(dy, T), dev(x, R), dev(mean), dev(rstd), dev(g), G, G, Gb, dg, db, gsum=gsum)
     assert_close("ln.g_out", G, gin + xr.grad, TOL[R])
+    assert_close("ln.gsum", gsum, (gin + xr.grad).sum(0), 2e-3 if R == torch.bfloat16 else 1e-4)
     if Gb is not None:
         assert_close("ln.gb_out", Gb, gin + xr.grad, TOL[T])
     assert_close("ln.dgamma", dg, gr.grad, 1e-4)

@@ -167,3 +167,30 @@ def test_vitb16_full_size_fp32_logits_within_1e3():
         worst = max(worst, abs(gn - gn_ref) / max(gn_ref, 1e-12))
     assert worst < 1e-3
     print(f"\nvitb16 fp32: logits rel err {e:.2e}, loss diff {abs(loss.item()-loss_ref.item()):.2e}, worst grad-norm rel {worst:.2e}")
+
+
+@pytest.mark.parametrize("residual", ["fp32", "bf16"])
+def test_vitb16_full_size_bf16_deviation_is_bounded(residual):
+    """Perf mode on the real architecture (dino_vitb16 @224, batch 4): the deviation from the
+    fp32 CPU oracle is MEASURED and bounded (logits 3e-2 rel, loss 2e-2, grad norms 8e-2);
+    bf16 operands cannot reach the 1e-3 parity bar, which the fp32 mode test above meets."""
+    from oracle import vit_ref
+    from vit_torch_amd import VisionModelZoo
+    ref = vit_ref.build("dino_vitb16", classifier=10)
+    vit_ref.seeded_init_(ref, 1)
+    m = VisionModelZoo.get_model("dino_vitb16", pretrained=False, classifier=10,
+                                 compute_dtype="bf16", residual_dtype=residual).cuda()
+    m.load_state_dict(ref.state_dict(), strict=True)
+    x, y = data(4, 3, 224, 10)
+    out_ref, loss_ref, out, loss, _ = run_step(ref, m, x, y, 10)
+    e = assert_close("vitb16 bf16 logits", out, out_ref, 3e-2)
+    assert abs(loss.item() - loss_ref.item()) < 2e-2
+    worst, worst_name = 0.0, ""
+    for (n, pr), (_, pm) in zip(ref.named_parameters(), m.named_parameters()):
+        gn_ref, gn = pr.grad.norm().item(), pm.grad.norm().item()
+        rel = abs(gn - gn_ref) / max(gn_ref, 1e-12)
+        if rel > worst:
+            worst, worst_name = rel, n
+    assert worst < 8e-2, f"{worst_name}: {worst}"
+    print(f"\nvitb16 bf16 (residual {residual}): logits rel err {e:.2e}, loss diff "
+          f"{abs(loss.item()-loss_ref.item()):.2e}, worst grad-norm rel {worst:.2e} ({worst_name})")

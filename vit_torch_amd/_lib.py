@@ -47,7 +47,7 @@ SIGNATURES = {
                                       c_vp, c_vp, c_i64, c_i64, c_f32, c_vp]),
     "vitmi_layernorm_bwd_workspace": (c_sz, [c_i64, c_i64]),
     "vitmi_layernorm_bwd": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, C.c_int, c_i64, c_vp, c_vp, c_vp,
-                                      c_vp, c_vp, C.c_int, c_i64, c_vp, C.c_int, c_i64, c_vp, c_vp,
+                                      c_vp, c_vp, C.c_int, c_i64, c_vp, C.c_int, c_i64, c_vp, c_vp, c_vp,
                                       c_i64, c_i64, c_vp, c_sz, c_vp]),
     "vitmi_attn_fwd": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_i64, c_f32, c_vp]),
     "vitmi_attn_bwd_workspace": (c_sz, [c_i64, c_i64, c_i64]),

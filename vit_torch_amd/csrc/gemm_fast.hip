@@ -443,26 +443,42 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
     if (g.e.bias) loadv<float, W>(g.e.bias + n0 + wn * 64 + rc, bias_r);
     if (MODE == VITMI_EPI_RESIDUAL && g.e.gamma) loadv<float, W>(g.e.gamma + n0 + wn * 64 + rc, gamma_r);
   }
+  constexpr int NJ = 16 / RPI;                     // row groups per strip
+  const bool side = !SPLITK && epi_has_side<MODE, TC>(g.e);
+  const int64_t ncol = n0 + wn * 64 + rc;
+  float sx[2][NJ][W];                              // side inputs: this strip and the next
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int i = 0; i < W; ++i) { sx[0][j][i] = 0.f; sx[1][j][i] = 0.f; }
+  if (side) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) epi_side<MODE, TC, W>(g.e, m0 + wm * 128 + j * RPI + rr, ncol, sx[0][j]);
+  }
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi) {
+    if (side && mi + 1 < 8) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        epi_side<MODE, TC, W>(g.e, m0 + wm * 128 + (mi + 1) * 16 + j * RPI + rr, ncol, sx[(mi + 1) & 1][j]);
+    }
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
       *reinterpret_cast<f32x4*>(tr + lr * TRS + ni * 16 + lg * 4) = acc[ni][mi];
 #pragma unroll
-    for (int j = 0; j < 16 / RPI; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       const int row = j * RPI + rr;
       float v[W];
 #pragma unroll
-      for (int q = 0; q < W / 4; ++q) {
-        const f32x4 t4 = *reinterpret_cast<const f32x4*>(tr + row * TRS + rc + 4 * q);
-        v[4 * q] = t4[0]; v[4 * q + 1] = t4[1]; v[4 * q + 2] = t4[2]; v[4 * q + 3] = t4[3];
+      for (int qq = 0; qq < W / 4; ++qq) {
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(tr + row * TRS + rc + 4 * qq);
+        v[4 * qq] = t4[0]; v[4 * qq + 1] = t4[1]; v[4 * qq + 2] = t4[2]; v[4 * qq + 3] = t4[3];
       }
       const int64_t m = m0 + wm * 128 + mi * 16 + row;
-      const int64_t n = n0 + wn * 64 + rc;
       if constexpr (SPLITK)
-        storev<float, W>(ws + ((int64_t)split * g.M + m) * g.N + n, v);
+        storev<float, W>(ws + ((int64_t)split * g.M + m) * g.N + ncol, v);
       else
-        epi_row<MODE, TC, W>(g.e, m, n, v, bias_r, gamma_r);
+        epi_row<MODE, TC, W>(g.e, m, ncol, v, bias_r, gamma_r, sx[mi & 1][j]);
     }
   }
 }
@@ -481,7 +497,9 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, E
     float b[4] = {0.f, 0.f, 0.f, 0.f};
     const float one[4] = {1.f, 1.f, 1.f, 1.f};
     if (e.bias) loadv<float, 4>(e.bias + n, b);
-    epi_row<VITMI_EPI_STORE, float, 4>(e, m, n, v, b, one);
+    float x[4] = {0.f, 0.f, 0.f, 0.f};
+    if (e.accumulate) epi_side<VITMI_EPI_STORE, float, 4>(e, m, n, x);
+    epi_row<VITMI_EPI_STORE, float, 4>(e, m, n, v, b, one, x);
   }
 }
 

@@ -115,19 +115,33 @@ __device__ __forceinline__ void storev(T* p, const float (&v)[W]) {
 // b / gm: bias and LayerScale of the lane's W columns (the same for every row, so the
 // caller loads them ONCE: a load inside the row loop would put a vmcnt wait, which also
 // counts the previous rows' stores, in front of every store)
+// does this epilogue read a per-element side input (residual / saved pre-activation / C)?
+template <int MODE, typename TC>
+__device__ __forceinline__ bool epi_has_side(const EpiArgs& e) {
+  if constexpr (MODE == VITMI_EPI_RESIDUAL || MODE == VITMI_EPI_DGELU) return true;
+  else if constexpr (MODE == VITMI_EPI_STORE && sizeof(TC) == 4) return e.accumulate != 0;
+  else return false;
+}
+// load it for W columns of row m: issued a whole strip ahead of its use, so the HBM
+// latency of the 128-512 KiB a tile reads here is not paid row by row
+template <int MODE, typename TC, int W>
+__device__ __forceinline__ void epi_side(const EpiArgs& e, int64_t m, int64_t n, float (&x)[W]) {
+  if constexpr (MODE == VITMI_EPI_RESIDUAL) loadv<TC, W>(reinterpret_cast<const TC*>(e.R) + m * e.ldr + n, x);
+  else if constexpr (MODE == VITMI_EPI_DGELU) loadv<bf16, W>(reinterpret_cast<const bf16*>(e.AUX) + m * e.ldaux + n, x);
+  else if constexpr (MODE == VITMI_EPI_STORE && sizeof(TC) == 4) loadv<float, W>(reinterpret_cast<const float*>(e.C) + m * e.ldc + n, x);
+}
+
 template <int MODE, typename TC, int W>
 __device__ __forceinline__ void epi_row(const EpiArgs& e, int64_t m, int64_t n, float (&v)[W],
-                                        const float (&b)[W], const float (&gm)[W]) {
+                                        const float (&b)[W], const float (&gm)[W], const float (&x)[W]) {
   TC* C = reinterpret_cast<TC*>(e.C);
   if constexpr (MODE == VITMI_EPI_STORE) {
 #pragma unroll
     for (int i = 0; i < W; ++i) v[i] = v[i] * e.alpha + b[i];
     if constexpr (sizeof(TC) == 4) {
       if (e.accumulate) {
-        float c[W];
-        loadv<float, W>(reinterpret_cast<const float*>(e.C) + m * e.ldc + n, c);
 #pragma unroll
-        for (int i = 0; i < W; ++i) v[i] += c[i];
+        for (int i = 0; i < W; ++i) v[i] += x[i];
       }
     }
   } else if constexpr (MODE == VITMI_EPI_BIAS_GELU) {
@@ -142,18 +156,14 @@ __device__ __forceinline__ void epi_row(const EpiArgs& e, int64_t m, int64_t n, 
     }
     if (e.C2) storev<TC, W>(reinterpret_cast<TC*>(e.C2) + m * e.ldc2 + n, pre);
   } else if constexpr (MODE == VITMI_EPI_RESIDUAL) {
-    float r[W];
-    loadv<TC, W>(reinterpret_cast<const TC*>(e.R) + m * e.ldr + n, r);
 #pragma unroll
-    for (int i = 0; i < W; ++i) v[i] = r[i] + gm[i] * (v[i] + b[i]);
+    for (int i = 0; i < W; ++i) v[i] = x[i] + gm[i] * (v[i] + b[i]);
   } else if constexpr (MODE == VITMI_EPI_DGELU) {
-    float a[W];
-    loadv<bf16, W>(reinterpret_cast<const bf16*>(e.AUX) + m * e.ldaux + n, a);
 #pragma unroll
     for (int i = 0; i < W; ++i) {
       float cdf, pdf;
-      gelu_parts(a[i], &cdf, &pdf);
-      v[i] *= cdf + a[i] * pdf;
+      gelu_parts(x[i], &cdf, &pdf);
+      v[i] *= cdf + x[i] * pdf;
     }
   } else {  // PATCH_POS
     const int64_t t = m % e.n_tok;

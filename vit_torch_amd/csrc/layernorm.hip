@@ -63,26 +63,28 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, i
 
 // Backward.  Each wave walks rows row0, row0+stride, ...; dgamma/dbeta are kept
 // per lane in registers, reduced over the block's 4 waves through LDS and
-// written as one partial row per block: part[blockIdx][0..D) = dgamma,
-// part[blockIdx][D..2D) = dbeta.  A second kernel sums the partial rows.
+// written as one partial row per block: part[blockIdx][0..D) = dgamma, [D..2D) = dbeta,
+// [2D..3D) = column sum of g_out (the bias gradient of the Linear that produced this
+// LayerNorm's input: it costs three adds per element here instead of a separate pass over
+// g_out).  reduce_rows sums the partial rows.
 template <typename TDY, typename TX, typename TG, typename TGB>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy, int64_t dys,
                                                      const TX* __restrict__ x, int64_t xs,
                                                      const float* __restrict__ mean,
                                                      const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma,
-                                                     const TG* g_in, TG* g_out, int64_t gs,
+                                                     const TG* g_in, TG* g_out, int64_t gstride,
                                                      TGB* __restrict__ gb_out, int64_t gbs,
-                                                     float* __restrict__ part,
+                                                     float* __restrict__ part, int want_gsum,
                                                      int64_t M, int D) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [4][D]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  f32x4 gam[LN_MAXV], dg[LN_MAXV], db[LN_MAXV];
+  f32x4 gam[LN_MAXV], dg[LN_MAXV], db[LN_MAXV], gs[LN_MAXV];
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
     const int c = (i * 64 + lane) * 4;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    dg[i] = z; db[i] = z; gam[i] = z;
+    dg[i] = z; db[i] = z; gam[i] = z; gs[i] = z;
     if (c < D) gam[i] = *reinterpret_cast<const f32x4*>(gamma + c);
   }
   const float invD = 1.f / (float)D;
@@ -118,23 +120,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = rs * (dv[i][j] - c1 - xh[i][j] * c2);
         if (g_in) {
-          const f32x4 gi = load4<TG>(g_in + row * gs + c);
+          const f32x4 gi = load4<TG>(g_in + row * gstride + c);
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[j] += gi[j];
         }
-        store4<TG>(g_out + row * gs + c, o);
+        store4<TG>(g_out + row * gstride + c, o);
         if (gb_out) store4<TGB>(gb_out + row * gbs + c, o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gs[i][j] += o[j];     // column sum of the outgoing gradient
       }
     }
   }
   // block reduction of dgamma then dbeta
-  float* prow = part + (int64_t)blockIdx.x * 2 * D;
+  float* prow = part + (int64_t)blockIdx.x * 3 * D;
 #pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
+  for (int pass = 0; pass < (want_gsum ? 3 : 2); ++pass) {
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
       const int c = (i * 64 + lane) * 4;
-      if (c < D) *reinterpret_cast<f32x4*>(red + w * D + c) = pass == 0 ? dg[i] : db[i];
+      if (c < D) *reinterpret_cast<f32x4*>(red + w * D + c) = pass == 0 ? dg[i] : (pass == 1 ? db[i] : gs[i]);
     }
     __syncthreads();
     for (int c = threadIdx.x; c < D; c += 256)
@@ -185,7 +189,7 @@ extern "C" int vitmi_layernorm_fwd(const void* x, int x_dtype, int64_t x_stride,
 }
 
 extern "C" size_t vitmi_layernorm_bwd_workspace(int64_t M, int64_t D) {
-  return (size_t)ln_bwd_blocks(M) * 2 * (size_t)D * sizeof(float);
+  return (size_t)ln_bwd_blocks(M) * 3 * (size_t)D * sizeof(float);
 }
 
 extern "C" int vitmi_layernorm_bwd(const void* dy, int dy_dtype, int64_t dy_stride, const void* x,
@@ -193,8 +197,8 @@ extern "C" int vitmi_layernorm_bwd(const void* dy, int dy_dtype, int64_t dy_stri
                                    const float* rstd, const float* gamma, const void* g_in,
                                    void* g_out, int g_dtype, int64_t g_stride, void* gb_out,
                                    int gb_dtype, int64_t gb_stride, float* dgamma, float* dbeta,
-                                   int64_t M, int64_t D, void* workspace, size_t workspace_bytes,
-                                   void* stream_) {
+                                   float* gsum, int64_t M, int64_t D, void* workspace,
+                                   size_t workspace_bytes, void* stream_) {
   int rc = check_ln_common(x, x_dtype, x_stride, M, D, "layernorm_bwd");
   if (rc) return rc;
   VITMI_REQUIRE(dy && mean && rstd && gamma && g_out && dgamma && dbeta, VITMI_E_BADARG, "layernorm_bwd: null argument");
@@ -214,7 +218,7 @@ extern "C" int vitmi_layernorm_bwd(const void* dy, int dy_dtype, int64_t dy_stri
 #define LN_BWD(TDY, TX, TG, TGB)                                                               \
   hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TG, TGB>), dim3(nblk), dim3(256), lds, stream,    \
                      (const TDY*)dy, dy_stride, (const TX*)x, x_stride, mean, rstd, gamma,     \
-                     (const TG*)g_in, (TG*)g_out, g_stride, (TGB*)gb_out, gb_stride, part, M, (int)D)
+                     (const TG*)g_in, (TG*)g_out, g_stride, (TGB*)gb_out, gb_stride, part, gsum ? 1 : 0, M, (int)D)
   const int gbd = gb_out ? gb_dtype : dy_dtype;
   if (dy_dtype == VITMI_F32 && x_dtype == VITMI_F32 && g_dtype == VITMI_F32 && gbd == VITMI_F32) LN_BWD(float, float, float, float);
   else if (dy_dtype == VITMI_BF16 && x_dtype == VITMI_F32 && g_dtype == VITMI_F32 && gbd == VITMI_BF16) LN_BWD(bf16, float, float, bf16);
@@ -224,7 +228,9 @@ extern "C" int vitmi_layernorm_bwd(const void* dy, int dy_dtype, int64_t dy_stri
 #undef LN_BWD
   rc = vitmi_check_launch("ln_bwd_kernel");
   if (rc) return rc;
-  rc = vitmi_reduce_rows(part, nblk, D, 2 * D, dgamma, stream);
+  rc = vitmi_reduce_rows(part, nblk, D, 3 * D, dgamma, stream);
   if (rc) return rc;
-  return vitmi_reduce_rows(part + D, nblk, D, 2 * D, dbeta, stream);
+  rc = vitmi_reduce_rows(part + D, nblk, D, 3 * D, dbeta, stream);
+  if (rc || !gsum) return rc;
+  return vitmi_reduce_rows(part + 2 * D, nblk, D, 3 * D, gsum, stream);
 }

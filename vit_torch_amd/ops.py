@@ -131,8 +131,8 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps, *, M=None, D=None, x_strid
     return y
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, g_in, g_out, gb_out, dgamma, dbeta, *, M=None, D=None,
-                  dy_stride=None, x_stride=None, g_stride=None, gb_stride=None):
+def layernorm_bwd(dy, x, mean, rstd, gamma, g_in, g_out, gb_out, dgamma, dbeta, *, gsum=None, M=None,
+                  D=None, dy_stride=None, x_stride=None, g_stride=None, gb_stride=None):
     _need_cuda(dy, x, g_out)
     D = D or x.shape[-1]
     M = M or dy.numel() // D
@@ -146,7 +146,7 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, g_in, g_out, gb_out, dgamma, dbeta, 
         _ptr(g_in), g_out.data_ptr(), dtype_code(g_out), g_stride if g_stride is not None else D,
         _ptr(gb_out), dtype_code(gb_out) if gb_out is not None else dtype_code(dy),
         gb_stride if gb_stride is not None else D,
-        dgamma.data_ptr(), dbeta.data_ptr(), M, D, ws.data_ptr(), ws.numel(), _stream()),
+        dgamma.data_ptr(), dbeta.data_ptr(), _ptr(gsum), M, D, ws.data_ptr(), ws.numel(), _stream()),
         "vitmi_layernorm_bwd")
 
 

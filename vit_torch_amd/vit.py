@@ -364,8 +364,11 @@ class VitEngine:
 
         # ---- final LayerNorm on the CLS rows -> residual-stream gradient G ----
         G = torch.zeros((M, D), dtype=R, device=dev)
+        # gsum of an LN backward = column sum of the gradient it leaves in G = the bias
+        # gradient of the Linear (fc2 / proj) that wrote that residual position
+        last_fc2_bias = m.blocks[-1].mlp.fc2.bias
         ops.layernorm_bwd(dfeat, s["Xf"], s["meanf"], s["rstdf"], pk.f32(m.norm.weight), None, G, None,
-                          pk.g(m.norm.weight), pk.g(m.norm.bias), M=B, D=D,
+                          pk.g(m.norm.weight), pk.g(m.norm.bias), gsum=pk.g(last_fc2_bias), M=B, D=D,
                           dy_stride=D, x_stride=N * D, g_stride=N * D)
         self._ready(m.norm, *([m.head] if self.head else []))
         if T == R:
@@ -376,7 +379,9 @@ class VitEngine:
         gb_out = None if T == R else Gb
 
         saved_blocks = s["blocks"]
-        for blk in reversed(m.blocks):
+        blocks_list = list(m.blocks)
+        for bi in range(len(blocks_list) - 1, -1, -1):
+            blk = blocks_list[bi]
             sv = saved_blocks.pop()      # release each block's activations as we go
             X, ln1, mean1, rstd1, qkv, O, lse, X1, ln2, mean2, rstd2, pre, hid = sv
             del sv
@@ -386,18 +391,17 @@ class VitEngine:
             dH = new(M, Dh, T)
             self._gemm(Gb, self._w(mlp.fc2.weight), dH, b_kmajor=False, epilogue=EPI_DGELU, aux=pre)
             self._gemm(Gb, hid, pk.g(mlp.fc2.weight), a_kmajor=False, b_kmajor=False)
-            ops.colsum(Gb, pk.g(mlp.fc2.bias))
             dln2 = new(M, D, T)
             self._gemm(dH, self._w(mlp.fc1.weight), dln2, b_kmajor=False)
             self._gemm(dH, ln2, pk.g(mlp.fc1.weight), a_kmajor=False, b_kmajor=False)
             ops.colsum(dH, pk.g(mlp.fc1.bias))
             ops.layernorm_bwd(dln2, X1, mean2, rstd2, pk.f32(blk.norm2.weight), G, G, gb_out,
-                              pk.g(blk.norm2.weight), pk.g(blk.norm2.bias), M=M, D=D)
+                              pk.g(blk.norm2.weight), pk.g(blk.norm2.bias), gsum=pk.g(a.proj.bias),
+                              M=M, D=D)
             # attention branch
             dO = new(M, D, T)
             self._gemm(Gb, self._w(a.proj.weight), dO, b_kmajor=False)
             self._gemm(Gb, O, pk.g(a.proj.weight), a_kmajor=False, b_kmajor=False)
-            ops.colsum(Gb, pk.g(a.proj.bias))
             dqkv = new(M, 3 * D, T)
             ops.attn_bwd(qkv, O, dO, lse, dqkv, B, N, H, hd, a.scale)
             dln1 = new(M, D, T)
@@ -405,8 +409,11 @@ class VitEngine:
             self._gemm(dqkv, ln1, pk.g(a.qkv.weight), a_kmajor=False, b_kmajor=False)
             if a.qkv.bias is not None:
                 ops.colsum(dqkv, pk.g(a.qkv.bias))
+            # the gradient this leaves in G flows into the previous block's fc2 output
+            prev_fc2_bias = blocks_list[bi - 1].mlp.fc2.bias if bi > 0 else None
             ops.layernorm_bwd(dln1, X, mean1, rstd1, pk.f32(blk.norm1.weight), G, G, gb_out,
-                              pk.g(blk.norm1.weight), pk.g(blk.norm1.bias), M=M, D=D)
+                              pk.g(blk.norm1.weight), pk.g(blk.norm1.bias),
+                              gsum=pk.g(prev_fc2_bias) if prev_fc2_bias is not None else None, M=M, D=D)
             self._ready(blk)
 
         # ---- embeddings ----
