@@ -61,7 +61,8 @@ enum {
                               models/swin.py:25-26)                           */
   VITMI_EPI_RESIDUAL = 2,  /* C = R + gamma[n]*(acc+bias[n])    (x + g*f(x),
                               models/cait.py:148-149, models/swin.py:267-268;
-                              gamma==NULL -> 1)                               */
+                              gamma==NULL -> 1); C2 (optional, dtype of A/B)
+                              = acc+bias, the branch output kept for d gamma  */
   VITMI_EPI_DGELU = 3,     /* C = acc * gelu_erf'(AUX)          (backward of
                               EPI_BIAS_GELU's activation)                     */
   VITMI_EPI_PATCH_POS = 4  /* t = m % n_tok:  t==0 ? cls[n]+pos[0,n]
@@ -78,7 +79,7 @@ typedef struct vitmi_gemm_desc {
   int32_t in_dtype;            /* dtype of A, B and AUX                       */
   int32_t epilogue;
   void* C; int64_t ldc; int32_t c_dtype;
-  void* C2; int64_t ldc2;      /* second output (same dtype as C) or NULL     */
+  void* C2; int64_t ldc2;      /* second output or NULL (dtype: see epilogues) */
   const float* bias;           /* [N] or NULL                                 */
   const void* R; int64_t ldr; int32_t r_dtype;   /* residual input           */
   const float* gamma;          /* [N] LayerScale or NULL                      */
@@ -89,6 +90,12 @@ typedef struct vitmi_gemm_desc {
   int32_t impl;                /* VITMI_GEMM_*                               */
   void* workspace;             /* optional scratch, >= vitmi_gemm_workspace(d) */
   size_t workspace_bytes;      /* (without it split-K is not used: slower)    */
+  /* batched form (generic kernel, EPI_STORE only): problem z = zo*batch_inner + zi,
+   * zo < batch/batch_inner, uses A + zo*a_bs[0] + zi*a_bs[1] (elements), same for B, C.
+   * Lets per-(image, head) products read q/k/v in place from the [B,N,3,H,hd] qkv
+   * tensor (models/cait.py:113).  batch <= 1 = plain GEMM. */
+  int64_t batch, batch_inner;
+  int64_t a_bs[2], b_bs[2], c_bs[2];
 } vitmi_gemm_desc;
 
 int vitmi_gemm(const vitmi_gemm_desc* d, void* stream);
@@ -116,13 +123,15 @@ size_t vitmi_layernorm_bwd_workspace(int64_t M, int64_t D);
 /* g_out = (g_in ? g_in : 0) + dLN/dx ; gb_out (optional) = cast(g_out);
  * dgamma/dbeta overwritten (fp32 [D]); gsum (optional, fp32 [D]) = column sum of g_out
  * over the M rows = the bias gradient of the Linear whose output feeds this residual
- * position (fused here to save a pass over g_out).  g_in may alias g_out. */
+ * position (fused here to save a pass over g_out).  gb_scale (optional, fp32 [D]):
+ * LayerScale of the branch that consumes gb_out — gb_out and gsum are then taken of
+ * g_out * gb_scale (models/cait.py:148-149).  g_in may alias g_out. */
 int vitmi_layernorm_bwd(const void* dy, int dy_dtype, int64_t dy_stride,
                         const void* x, int x_dtype, int64_t x_stride,
                         const float* mean, const float* rstd, const float* gamma,
                         const void* g_in, void* g_out, int g_dtype, int64_t g_stride,
                         void* gb_out, int gb_dtype, int64_t gb_stride,
-                        float* dgamma, float* dbeta, float* gsum,
+                        float* dgamma, float* dbeta, float* gsum, const float* gb_scale,
                         int64_t M, int64_t D,
                         void* workspace, size_t workspace_bytes, void* stream);
 
@@ -143,10 +152,48 @@ int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout,
                    int64_t B, int64_t N, int64_t H, int64_t hd, float scale,
                    void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------- CaiT ops --
+ * Talking-heads softmax (models/cait.py:118-122) on score tensors [B,H,N,ld] (row length
+ * Nk <= 256 valid columns, H <= 8):  S' = Wl S + bl over the head axis, P = softmax_j(S'),
+ * Pm = Ww P + bw.  P is kept for backward.  The q k^T, P v products around it are batched
+ * vitmi_gemm calls that read q/k/v in place from the qkv tensor. */
+int vitmi_th_softmax_fwd(const void* S, const float* Wl, const float* bl, const float* Ww,
+                         const float* bw, void* P, void* Pm, int dtype,
+                         int64_t B, int64_t H, int64_t N, int64_t Nk, int64_t ld, void* stream);
+size_t vitmi_th_softmax_bwd_workspace(int64_t B, int64_t H, int64_t N);
+/* dS from dPm; dWl/dbl/dWw/dbw (fp32, overwritten) = gradients of proj_l / proj_w */
+int vitmi_th_softmax_bwd(const void* S, const void* P, const void* dPm, const float* Wl,
+                         const float* Ww, void* dS, float* dWl, float* dbl, float* dWw, float* dbw,
+                         int dtype, int64_t B, int64_t H, int64_t N, int64_t Nk, int64_t ld,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* Class attention core (models/cait.py:44-52): one query per image (the projected CLS
+ * token, q [B, H*hd]) against k/v rows [B, N, .] with token stride kv_token_stride
+ * (elements); out [B, H*hd]; p_save [B,H,N] fp32 (softmax, kept for backward). */
+int vitmi_class_attn_fwd(const void* q, const void* k, const void* v, int64_t kv_token_stride,
+                         void* out, float* p_save, int dtype,
+                         int64_t B, int64_t H, int64_t N, int64_t hd, float scale, void* stream);
+int vitmi_class_attn_bwd(const void* q, const void* k, const void* v, int64_t kv_token_stride,
+                         const void* dout, const float* p_save, void* dq, void* dk, void* dv,
+                         int64_t dkv_token_stride, int dtype,
+                         int64_t B, int64_t H, int64_t N, int64_t hd, float scale, void* stream);
+
+/* out[n] = sum_m x[m*ldx+n] * y[m*ldy+n]: LayerScale gradient d gamma = sum_rows dY * f(x)
+ * (models/cait.py:148-149) */
+size_t vitmi_colsum_mul_workspace(int64_t M, int64_t N);
+int vitmi_colsum_mul(const void* x, int x_dtype, int64_t ldx, const void* y, int y_dtype, int64_t ldy,
+                     int64_t M, int64_t N, float* out, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
 /* ---------------------------------------------------------- Elementwise --*/
 /* fp32 -> bf16 shadow copy of the flat parameter buffer */
 int vitmi_cast(const void* src, int src_dtype, void* dst, int dst_dtype,
                int64_t n, void* stream);
+
+/* out[m*ldo+n] = cast(x[m*ldx+n] * scale[n]) (scale NULL -> 1): strided row copy with an
+ * optional per-column LayerScale; also the plain strided copy/cast of row blocks */
+int vitmi_scale_cast(const void* x, int x_dtype, int64_t ldx, const float* scale,
+                     void* out, int out_dtype, int64_t ldo, int64_t M, int64_t N, void* stream);
 
 /* im2col for Conv2d(C, D, kernel=p, stride=p) (models/swin.py:434,445):
  * x[B,C,H,W] fp32 with element strides (sb,sc,sh,sw) — NCHW or channels_last —

@@ -1,0 +1,208 @@
+"""CaiT on the HIP path against the CPU oracle (oracle/cait_ref.py, itself pinned to the
+reference by tests/golden/*.npz), plus the CaiT-specific ops against plain PyTorch math."""
+from functools import partial
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from util import assert_close, bf16_round
+
+pytestmark = pytest.mark.gpu
+
+
+def gen(shape, seed, scale=1.0):
+    return torch.randn(shape, generator=torch.Generator("cpu").manual_seed(seed)) * scale
+
+
+@pytest.fixture(scope="module")
+def ops(lib):
+    from vit_torch_amd import ops as _o
+    return _o
+
+
+# ------------------------------------------------------------------------ ops ---
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,N", [(2, 4, 10), (3, 8, 196), (1, 1, 65)])
+def test_th_softmax_fwd_bwd(ops, dt, B, H, N):
+    NS = (N + 7) // 8 * 8
+    rd = bf16_round if dt == torch.bfloat16 else (lambda t: t)
+    S = rd(gen((B, H, N, N), 1))
+    Wl, bl, Ww, bw = gen((H, H), 2, 0.5), gen((H,), 3, 0.1), gen((H, H), 4, 0.5), gen((H,), 5, 0.1)
+    dPm = rd(gen((B, H, N, N), 6))
+    Sr = S.clone().requires_grad_(True)
+    prm = [t.clone().requires_grad_(True) for t in (Wl, bl, Ww, bw)]
+    Sp = F.linear(Sr.permute(0, 2, 3, 1), prm[0], prm[1]).permute(0, 3, 1, 2)
+    Pr = Sp.softmax(-1)
+    Pmr = F.linear(Pr.permute(0, 2, 3, 1), prm[2], prm[3]).permute(0, 3, 1, 2)
+    Pmr.backward(dPm)
+    pad = lambda t: F.pad(t, (0, NS - N)).to("cuda", dt).contiguous()
+    Sd, P, Pm = pad(S), torch.zeros((B, H, N, NS), device="cuda", dtype=dt), torch.zeros((B, H, N, NS), device="cuda", dtype=dt)
+    c = lambda t: t.cuda()
+    ops.th_softmax_fwd(Sd, c(Wl), c(bl), c(Ww), c(bw), P, Pm, B, H, N, N, NS)
+    tol = 2e-5 if dt == torch.float32 else 1.5e-2
+    assert_close("P", P[..., :N], Pr.detach(), tol)
+    assert_close("Pm", Pm[..., :N], Pmr.detach(), tol)
+    dS = torch.zeros_like(Sd)
+    g = [torch.empty(H * H, device="cuda"), torch.empty(H, device="cuda"), torch.empty(H * H, device="cuda"), torch.empty(H, device="cuda")]
+    ops.th_softmax_bwd(Sd, P, pad(dPm), c(Wl), c(Ww), dS, g[0], g[1], g[2], g[3], B, H, N, N, NS)
+    assert_close("dS", dS[..., :N], Sr.grad, 1e-4 if dt == torch.float32 else 3e-2)
+    gt = 1e-4 if dt == torch.float32 else 3e-2
+    assert_close("dWl", g[0].view(H, H), prm[0].grad, gt)
+    assert_close("dbl", g[1], prm[1].grad, gt)
+    assert_close("dWw", g[2].view(H, H), prm[2].grad, gt)
+    assert_close("dbw", g[3], prm[3].grad, gt)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,N,hd", [(3, 4, 11, 12), (2, 8, 197, 48), (1, 2, 64, 64)])
+def test_class_attention_core(ops, dt, B, H, N, hd):
+    rd = bf16_round if dt == torch.bfloat16 else (lambda t: t)
+    D = H * hd
+    scale = hd ** -0.5
+    q, k, v, do = rd(gen((B, D), 1)), rd(gen((B, N, D), 2)), rd(gen((B, N, D), 3)), rd(gen((B, D), 4))
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    qh = qr.view(B, 1, H, hd).permute(0, 2, 1, 3) * scale
+    kh, vh = kr.view(B, N, H, hd).permute(0, 2, 1, 3), vr.view(B, N, H, hd).permute(0, 2, 1, 3)
+    o = ((qh @ kh.transpose(-2, -1)).softmax(-1) @ vh).transpose(1, 2).reshape(B, D)
+    o.backward(do)
+    dev = lambda t: t.to("cuda", dt).contiguous()
+    out = torch.empty((B, D), device="cuda", dtype=dt)
+    ps = torch.empty(B * H * N, device="cuda")
+    ops.class_attn_fwd(dev(q), dev(k), dev(v), D, out, ps, B, H, N, hd, scale)
+    tol = 2e-5 if dt == torch.float32 else 1.5e-2
+    assert_close("ca.out", out, o.detach(), tol)
+    dq = torch.empty((B, D), device="cuda", dtype=dt)
+    dk = torch.full((B, N, D), float("nan"), device="cuda").to(dt)
+    dv = torch.full((B, N, D), float("nan"), device="cuda").to(dt)
+    ops.class_attn_bwd(dev(q), dev(k), dev(v), D, dev(do), ps, dq, dk, dv, D, B, H, N, hd, scale)
+    bt = 5e-5 if dt == torch.float32 else 2.5e-2
+    assert_close("ca.dq", dq, qr.grad, bt)
+    assert_close("ca.dk", dk, kr.grad, bt)
+    assert_close("ca.dv", dv, vr.grad, bt)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_batched_gemm_on_qkv_views(ops, dt):
+    """scores and P@V read q/k/v in place from [B, N, 3, H, hd] (models/cait.py:113-126)."""
+    B, N, H, hd = 2, 37, 3, 48
+    NS = (N + 7) // 8 * 8
+    D3 = 3 * H * hd
+    rd = bf16_round if dt == torch.bfloat16 else (lambda t: t)
+    qkv = rd(gen((B, N, D3), 1))
+    q, k, v = qkv.view(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    Sref = (q @ k.transpose(-2, -1)) * 0.25
+    Q = qkv.to("cuda", dt)
+    S = torch.zeros((B, H, N, NS), device="cuda", dtype=dt)
+    ops.gemm_batched(Q, Q, S, M=N, N=N, K=hd, lda=D3, ldb=D3, ldc=NS, a_kmajor=True, b_kmajor=True,
+                     batch=B * H, batch_inner=H, a_bs=(N * D3, hd), b_bs=(N * D3, hd), c_bs=(H * N * NS, N * NS),
+                     b_off=H * hd, alpha=0.25)
+    tol = 2e-5 if dt == torch.float32 else 1.5e-2
+    assert_close("scores", S[..., :N], Sref, tol)
+    Pm = rd(gen((B, H, N, N), 2).softmax(-1))
+    Oref = (Pm @ v).transpose(1, 2).reshape(B, N, H * hd)
+    Pd = F.pad(Pm, (0, NS - N)).to("cuda", dt).contiguous()
+    O = torch.zeros((B, N, H * hd), device="cuda", dtype=dt)
+    ops.gemm_batched(Pd, Q, O, M=N, N=hd, K=N, lda=NS, ldb=D3, ldc=H * hd, a_kmajor=True, b_kmajor=False,
+                     batch=B * H, batch_inner=H, a_bs=(H * N * NS, N * NS), b_bs=(N * D3, hd), c_bs=(N * H * hd, hd),
+                     b_off=2 * H * hd)
+    assert_close("PV", O, Oref, tol)
+
+
+def test_colsum_mul_and_scale_cast(ops):
+    M, N = 333, 96
+    x, y, sc = gen((M, N), 1), bf16_round(gen((M, N), 2)), gen((N,), 3)
+    out = torch.empty(N, device="cuda")
+    ops.colsum_mul(x.cuda(), y.cuda().bfloat16(), out)
+    assert_close("colsum_mul", out, (x * y).sum(0), 1e-5)
+    o2 = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+    ops.scale_cast(x.cuda(), o2, sc.cuda(), M=M, N=N)
+    assert torch.equal(o2.cpu(), (x * sc).bfloat16())
+
+
+# ---------------------------------------------------------------------- model ---
+TINY = dict(img_size=32, patch_size=8, embed_dim=64, depth=2, num_heads=4, mlp_ratio=4, qkv_bias=True,
+            norm_layer=partial(nn.LayerNorm, eps=1e-6), init_scale=1e-1, depth_token_only=2, num_classes=10)
+
+
+def make_pair(cfg, compute, residual="fp32"):
+    from oracle.cait_ref import CaiT
+    from oracle.vit_ref import seeded_init_
+    from vit_torch_amd import cait_models
+    ref = CaiT(**cfg)
+    seeded_init_(ref, 3)
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if "gamma_" in n:
+                p.copy_(0.3 + 0.1 * torch.randn(p.shape, generator=torch.Generator("cpu").manual_seed(len(n))))
+    m = cait_models(**cfg, compute_dtype=compute, residual_dtype=residual)
+    res = m.load_state_dict(ref.state_dict(), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    return ref, m.cuda()
+
+
+def step(ref, m, B, S):
+    from vit_torch_amd import CrossEntropyLoss
+    g = torch.Generator("cpu").manual_seed(0)
+    x, y = torch.randn(B, 3, S, S, generator=g), torch.randint(0, 10, (B,), generator=g)
+    lo = ref(x)
+    lr = F.cross_entropy(lo, y)
+    ref.zero_grad(); lr.backward()
+    out = m(x.cuda())
+    loss = CrossEntropyLoss()(out, y.cuda())
+    m.zero_grad(); loss.backward()
+    return lo.detach(), lr.detach(), out.detach(), loss.detach()
+
+
+def test_cait_tiny_fp32_matches_oracle():
+    ref, m = make_pair(TINY, "fp32")
+    lo, lr, out, loss = step(ref, m, 5, 32)
+    e = assert_close("logits", out, lo, 1e-4)
+    assert abs(loss.item() - lr.item()) < 1e-4
+    worst = 0.0
+    for (n, pr), (n2, pm) in zip(ref.named_parameters(), m.named_parameters()):
+        assert n == n2
+        worst = max(worst, assert_close(f"grad[{n}]", pm.grad, pr.grad, 3e-4))
+    print(f"\ncait tiny fp32: logits rel err {e:.2e}, worst grad rel err {worst:.2e}")
+
+
+@pytest.mark.parametrize("residual", ["fp32", "bf16"])
+def test_cait_tiny_bf16_close_to_oracle(residual):
+    ref, m = make_pair(TINY, "bf16", residual)
+    lo, lr, out, loss = step(ref, m, 6, 32)
+    e = assert_close("logits", out, lo, 3e-2)
+    assert abs(loss.item() - lr.item()) < 2e-2
+    worst = 0.0
+    for (n, pr), (_, pm) in zip(ref.named_parameters(), m.named_parameters()):
+        gn_ref, gn = pr.grad.norm().item(), pm.grad.float().norm().item()
+        rel = abs(gn - gn_ref) / max(gn_ref, 1e-12)
+        worst = max(worst, rel)
+        assert rel < 8e-2, f"grad-norm[{n}]: {gn:.4g} vs {gn_ref:.4g}"
+    print(f"\ncait tiny bf16 (residual {residual}): logits rel err {e:.2e}, worst grad-norm rel err {worst:.2e}")
+
+
+def test_cait_s24_224_full_size_fp32_logits_within_1e3():
+    """BASELINE config 4 architecture, batch 2, parity mode."""
+    from oracle import cait_ref
+    from oracle.vit_ref import seeded_init_
+    from vit_torch_amd import VisionModelZoo
+    ref = cait_ref.build("cait_S24_224", num_classes=10)
+    seeded_init_(ref, 5)
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if "gamma_" in n:
+                p.fill_(0.1)
+    m = VisionModelZoo.get_model("cait_S24_224", pretrained=False, classifier=None, compute_dtype="fp32")
+    m.head = nn.Linear(384, 10)
+    m.load_state_dict(ref.state_dict(), strict=True)
+    m = m.cuda()
+    lo, lr, out, loss = step(ref, m, 2, 224)
+    e = assert_close("cait_S24_224 logits", out, lo, 1e-3)
+    assert abs(loss.item() - lr.item()) < 1e-3
+    worst = 0.0
+    for (n, pr), (_, pm) in zip(ref.named_parameters(), m.named_parameters()):
+        gn_ref, gn = pr.grad.norm().item(), pm.grad.norm().item()
+        worst = max(worst, abs(gn - gn_ref) / max(gn_ref, 1e-12))
+    assert worst < 2e-3
+    print(f"\ncait_S24_224 fp32: logits rel err {e:.2e}, loss diff {abs(loss.item()-lr.item()):.2e}, worst grad-norm rel {worst:.2e}")

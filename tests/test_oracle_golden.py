@@ -94,3 +94,39 @@ def test_state_dict_names_match_oracle():
     assert list(ref.state_dict().keys()) == list(m.state_dict().keys())
     for (k, a), (_, b) in zip(ref.state_dict().items(), m.state_dict().items()):
         assert a.shape == b.shape, k
+
+
+# ------------------------------------------------------------------- CaiT oracle ---
+def test_cait_talking_heads_matches_reference():
+    from oracle.cait_ref import TalkingHeadAttention
+    top, groups = load("talking_heads")
+    check_module(TalkingHeadAttention(48, num_heads=4, qkv_bias=True), top, groups)
+
+
+def test_cait_class_attention_matches_reference():
+    from oracle.cait_ref import ClassAttention
+    top, groups = load("class_attention")
+    check_module(ClassAttention(48, num_heads=4, qkv_bias=True), top, groups)
+
+
+def test_cait_layerscale_block_matches_reference():
+    from oracle.cait_ref import LayerScaleBlock
+    top, groups = load("layerscale_block")
+    check_module(LayerScaleBlock(48, 4, 4.0, True, partial(nn.LayerNorm, eps=1e-6), 1e-1), top, groups)
+
+
+def test_cait_tiny_model_matches_reference():
+    import torch.nn.functional as F
+    from oracle.cait_ref import CaiT
+    top, groups = load("cait_tiny")
+    m = CaiT(img_size=32, patch_size=8, embed_dim=64, depth=2, num_heads=4, mlp_ratio=4, qkv_bias=True,
+             norm_layer=partial(nn.LayerNorm, eps=1e-6), init_scale=1e-1, depth_token_only=2, num_classes=10)
+    res = m.load_state_dict(groups["state"], strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    logits = m(top["x"])
+    assert_close("logits", logits, top["logits"], 2e-6)
+    loss = F.cross_entropy(logits, top["labels"])
+    assert abs(loss.item() - top["loss"].item()) < 1e-6
+    loss.backward()
+    for n, p in m.named_parameters():
+        assert_close(f"grad[{n}]", p.grad, groups["grad"][n], 2e-5)

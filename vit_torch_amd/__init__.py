@@ -4,5 +4,6 @@ from .loss import CrossEntropyLoss  # noqa: F401
 from .optim import FusedSGD  # noqa: F401
 from .vision_all import VisionModelZoo  # noqa: F401
 from .vit import VisionTransformer  # noqa: F401
+from .cait import cait_models  # noqa: F401
 
 __all__ = ["VisionModelZoo", "VisionTransformer", "CrossEntropyLoss", "FusedSGD", "VitmiError"]

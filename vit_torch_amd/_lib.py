@@ -33,6 +33,8 @@ class GemmDesc(C.Structure):
         ("pos", c_vp), ("n_tok", c_i64), ("cls", c_vp),
         ("alpha", c_f32), ("accumulate", c_i32), ("impl", c_i32),
         ("workspace", c_vp), ("workspace_bytes", c_sz),
+        ("batch", c_i64), ("batch_inner", c_i64),
+        ("a_bs", c_i64 * 2), ("b_bs", c_i64 * 2), ("c_bs", c_i64 * 2),
     ]
 
 
@@ -47,13 +49,23 @@ SIGNATURES = {
                                       c_vp, c_vp, c_i64, c_i64, c_f32, c_vp]),
     "vitmi_layernorm_bwd_workspace": (c_sz, [c_i64, c_i64]),
     "vitmi_layernorm_bwd": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, C.c_int, c_i64, c_vp, c_vp, c_vp,
-                                      c_vp, c_vp, C.c_int, c_i64, c_vp, C.c_int, c_i64, c_vp, c_vp, c_vp,
+                                      c_vp, c_vp, C.c_int, c_i64, c_vp, C.c_int, c_i64, c_vp, c_vp, c_vp, c_vp,
                                       c_i64, c_i64, c_vp, c_sz, c_vp]),
     "vitmi_attn_fwd": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_i64, c_f32, c_vp]),
     "vitmi_attn_bwd_workspace": (c_sz, [c_i64, c_i64, c_i64]),
     "vitmi_attn_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_i64,
                                  c_f32, c_vp, c_sz, c_vp]),
+    "vitmi_th_softmax_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp]),
+    "vitmi_th_softmax_bwd_workspace": (c_sz, [c_i64, c_i64, c_i64]),
+    "vitmi_th_softmax_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int,
+                                       c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_sz, c_vp]),
+    "vitmi_class_attn_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_i64, c_f32, c_vp]),
+    "vitmi_class_attn_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int,
+                                       c_i64, c_i64, c_i64, c_i64, c_f32, c_vp]),
+    "vitmi_colsum_mul_workspace": (c_sz, [c_i64, c_i64]),
+    "vitmi_colsum_mul": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, C.c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_sz, c_vp]),
     "vitmi_cast": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, c_i64, c_vp]),
+    "vitmi_scale_cast": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_vp]),
     "vitmi_patchify": (C.c_int, [c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, C.c_int, c_i64, c_i64,
                                  c_i64, c_i64, c_i64, C.c_int, c_vp]),
     "vitmi_colsum_workspace": (c_sz, [c_i64, c_i64]),

@@ -29,6 +29,7 @@ SOURCES = [
     "elementwise.hip",
     "attention.hip",
     "attention_f32.hip",
+    "cait_ops.hip",
 ]
 HEADERS = ["common.h", "epilogue.h", "gemm_tile.h", "../../include/vitmi.h"]
 

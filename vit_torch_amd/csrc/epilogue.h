@@ -6,7 +6,7 @@
 struct EpiArgs {
   int mode;
   void* C; int64_t ldc; int c_bf16;
-  void* C2; int64_t ldc2;
+  void* C2; int64_t ldc2; int c2_bf16;
   const float* bias;
   const void* R; int64_t ldr; int r_bf16;
   const float* gamma;
@@ -22,6 +22,8 @@ struct GemmArgs {
   const void* B; int64_t ldb; int b_km;
   void* ws; size_t ws_bytes;      // optional scratch (split-K partial tiles)
   unsigned long long* dbg;        // diagnostic phase stamps (NULL in production)
+  int64_t batch, batch_inner, a_bs[2], b_bs[2], c_bs[2];   // batched form (generic kernel)
+  int vec_a, vec_b;               // operand rows are 16-B aligned: vector staging allowed
   EpiArgs e;
 };
 
@@ -52,6 +54,7 @@ __device__ __forceinline__ float epi_value(const EpiArgs& e, int64_t m, int64_t 
     return gelu_erf(pre);
   } else if constexpr (MODE == VITMI_EPI_RESIDUAL) {
     float v = acc + (e.bias ? e.bias[n] : 0.f);
+    *v2 = v;                               // branch output before LayerScale (for d gamma)
     if (e.gamma) v *= e.gamma[n];
     return ld_any(e.R, m * e.ldr + n, e.r_bf16) + v;
   } else if constexpr (MODE == VITMI_EPI_DGELU) {
@@ -69,8 +72,8 @@ __device__ __forceinline__ void epi_store1(const EpiArgs& e, int64_t m, int64_t 
   float v2 = 0.f;
   const float v = epi_value<MODE>(e, m, n, acc, &v2);
   st_any(e.C, m * e.ldc + n, e.c_bf16, v);
-  if constexpr (MODE == VITMI_EPI_BIAS_GELU) {
-    if (e.C2) st_any(e.C2, m * e.ldc2 + n, e.c_bf16, v2);
+  if constexpr (MODE == VITMI_EPI_BIAS_GELU || MODE == VITMI_EPI_RESIDUAL) {
+    if (e.C2) st_any(e.C2, m * e.ldc2 + n, e.c2_bf16, v2);
   }
 }
 

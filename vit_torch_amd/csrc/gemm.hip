@@ -25,12 +25,51 @@ template <> struct GenericTraits<bf16> { static constexpr int LDK = 40; };   // 
 template <> struct GenericTraits<float> { static constexpr int LDK = 33; };
 
 // stage a [64 rows][32 k] tile of op(X) into LDS as [row][k], zero-filling
-// everything outside (rows_total, K)
+// everything outside (rows_total, K).  `vec`: rows start 16-B aligned and the leading
+// dimension keeps them so -> 16-B global loads along the contiguous dimension for the
+// interior of the matrix (edges fall back to the element-wise path).
 template <typename T>
 __device__ __forceinline__ void stage_tile(T* lds, const T* X, int64_t ld, int kmajor,
                                            int64_t row0, int64_t rows_total, int64_t k0,
-                                           int64_t K, int tid) {
+                                           int64_t K, int tid, int vec) {
   constexpr int LDK = GenericTraits<T>::LDK;
+  constexpr int V = 16 / sizeof(T);                 // elements per 16-B vector
+  if (vec) {
+    const bool interior = kmajor ? (k0 + GBK <= K) : (row0 + GBM <= rows_total);
+    if (interior) {
+      constexpr int NVEC = GBM * GBK / V;           // 256 (bf16) or 512 (fp32) vectors
+#pragma unroll
+      for (int i = 0; i < NVEC / 256; ++i) {
+        const int idx = tid + i * 256;
+        if (kmajor) {                               // vector along k
+          const int r = idx / (GBK / V), kc = (idx % (GBK / V)) * V;
+          const int64_t gr = row0 + r;
+          if (gr < rows_total) {
+            const auto v = *reinterpret_cast<const f32x4*>(X + gr * ld + k0 + kc);
+            const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+            for (int j = 0; j < V; ++j) lds[r * LDK + kc + j] = e[j];
+          } else {
+#pragma unroll
+            for (int j = 0; j < V; ++j) lds[r * LDK + kc + j] = from_f32<T>(0.f);
+          }
+        } else {                                    // vector along the row index
+          const int kk = idx / (GBM / V), rc = (idx % (GBM / V)) * V;
+          const int64_t gk = k0 + kk;
+          if (gk < K) {
+            const auto v = *reinterpret_cast<const f32x4*>(X + gk * ld + row0 + rc);
+            const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+            for (int j = 0; j < V; ++j) lds[(rc + j) * LDK + kk] = e[j];
+          } else {
+#pragma unroll
+            for (int j = 0; j < V; ++j) lds[(rc + j) * LDK + kk] = from_f32<T>(0.f);
+          }
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < (GBM * GBK) / 256; ++i) {
     const int idx = tid + i * 256;
@@ -55,14 +94,21 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs g) {
   const int64_t m0 = (int64_t)blockIdx.y * GBM, n0 = (int64_t)blockIdx.x * GBN;
   const T* A = reinterpret_cast<const T*>(g.A);
   const T* B = reinterpret_cast<const T*>(g.B);
+  if (g.batch > 1) {
+    const int64_t z = blockIdx.z, zo = z / g.batch_inner, zi = z % g.batch_inner;
+    A += zo * g.a_bs[0] + zi * g.a_bs[1];
+    B += zo * g.b_bs[0] + zi * g.b_bs[1];
+    const int64_t co = zo * g.c_bs[0] + zi * g.c_bs[1];
+    g.e.C = reinterpret_cast<char*>(g.e.C) + co * (g.e.c_bf16 ? 2 : 4);
+  }
 
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
   for (int64_t k0 = 0; k0 < g.K; k0 += GBK) {
-    stage_tile<T>(As, A, g.lda, g.a_km, m0, g.M, k0, g.K, tid);
-    stage_tile<T>(Bs, B, g.ldb, g.b_km, n0, g.N, k0, g.K, tid);
+    stage_tile<T>(As, A, g.lda, g.a_km, m0, g.M, k0, g.K, tid, g.vec_a);
+    stage_tile<T>(Bs, B, g.ldb, g.b_km, n0, g.N, k0, g.K, tid, g.vec_b);
     __syncthreads();
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -110,11 +156,26 @@ static int build_args(const vitmi_gemm_desc* d, GemmArgs* out) {
   g.B = d->B; g.ldb = d->ldb; g.b_km = d->b_kmajor ? 1 : 0;
   g.ws = d->workspace; g.ws_bytes = d->workspace_bytes;
   g.dbg = g_gemm_dbg;
+  g.batch = d->batch > 1 ? d->batch : 1;
+  g.batch_inner = d->batch_inner > 0 ? d->batch_inner : 1;
+  for (int i = 0; i < 2; ++i) { g.a_bs[i] = d->a_bs[i]; g.b_bs[i] = d->b_bs[i]; g.c_bs[i] = d->c_bs[i]; }
+  {
+    const size_t es = dtype_size(d->in_dtype);
+    const int64_t v = 16 / (int64_t)es;
+    auto ok = [&](const void* p, int64_t ld, const int64_t* bs) {
+      return is_aligned(p, 16) && ld % v == 0 && (g.batch == 1 || (bs[0] % v == 0 && bs[1] % v == 0));
+    };
+    g.vec_a = ok(d->A, d->lda, d->a_bs) ? 1 : 0;
+    g.vec_b = ok(d->B, d->ldb, d->b_bs) ? 1 : 0;
+  }
   if (g.ws && !is_aligned(g.ws, 16)) { g.ws = nullptr; g.ws_bytes = 0; }
   EpiArgs& e = g.e;
   e.mode = d->epilogue;
   e.C = d->C; e.ldc = d->ldc; e.c_bf16 = d->c_dtype == VITMI_BF16;
   e.C2 = d->C2; e.ldc2 = d->ldc2;
+  // second output: pre-activation in C's dtype (BIAS_GELU) / un-scaled branch output in the
+  // operand dtype (RESIDUAL with LayerScale, kept for d gamma)
+  e.c2_bf16 = d->epilogue == VITMI_EPI_RESIDUAL ? (d->in_dtype == VITMI_BF16) : (d->c_dtype == VITMI_BF16);
   e.bias = d->bias;
   e.R = d->R; e.ldr = d->ldr; e.r_bf16 = d->r_dtype == VITMI_BF16;
   e.gamma = d->gamma;
@@ -122,6 +183,8 @@ static int build_args(const vitmi_gemm_desc* d, GemmArgs* out) {
   e.pos = d->pos; e.n_tok = d->n_tok; e.ldpos = d->N; e.cls = d->cls;
   e.alpha = d->alpha == 0.f ? 1.f : d->alpha;
   e.accumulate = d->accumulate;
+  VITMI_REQUIRE(g.batch == 1 || (d->epilogue == VITMI_EPI_STORE && !d->accumulate && g.batch % g.batch_inner == 0 && g.batch <= 65535),
+                VITMI_E_BADARG, "gemm: batched form supports EPI_STORE without accumulate, batch %% batch_inner == 0, batch <= 65535");
   switch (d->epilogue) {
     case VITMI_EPI_STORE:
       VITMI_REQUIRE(!d->accumulate || d->c_dtype == VITMI_F32, VITMI_E_DTYPE, "gemm: accumulate needs an fp32 C");
@@ -130,6 +193,7 @@ static int build_args(const vitmi_gemm_desc* d, GemmArgs* out) {
       VITMI_REQUIRE(!d->C2 || d->ldc2 >= d->N, VITMI_E_BADARG, "gemm: ldc2 too small");
       break;
     case VITMI_EPI_RESIDUAL:
+      VITMI_REQUIRE(!d->C2 || d->ldc2 >= d->N, VITMI_E_BADARG, "gemm: ldc2 too small");
       VITMI_REQUIRE(d->R && d->ldr >= d->N, VITMI_E_BADARG, "gemm: EPI_RESIDUAL needs R with ldr >= N");
       VITMI_REQUIRE(d->r_dtype == d->c_dtype, VITMI_E_DTYPE, "gemm: EPI_RESIDUAL needs r_dtype == c_dtype");
       break;
@@ -147,14 +211,14 @@ static int build_args(const vitmi_gemm_desc* d, GemmArgs* out) {
 extern "C" int vitmi_gemm_uses_fast(const vitmi_gemm_desc* d) {
   GemmArgs g;
   if (build_args(d, &g) != 0) return 0;
-  if (d->impl == VITMI_GEMM_GENERIC) return 0;
+  if (d->impl == VITMI_GEMM_GENERIC || g.batch > 1) return 0;
   return gemm_fast_supported(g, d->in_dtype == VITMI_BF16) ? 1 : 0;
 }
 
 extern "C" size_t vitmi_gemm_workspace(const vitmi_gemm_desc* d) {
   GemmArgs g;
   if (build_args(d, &g) != 0 || d->impl == VITMI_GEMM_GENERIC) return 0;
-  if (!gemm_fast_supported(g, d->in_dtype == VITMI_BF16)) return 0;
+  if (g.batch > 1 || !gemm_fast_supported(g, d->in_dtype == VITMI_BF16)) return 0;
   return gemm_fast_workspace(g);
 }
 
@@ -164,13 +228,13 @@ extern "C" int vitmi_gemm(const vitmi_gemm_desc* d, void* stream_) {
   if (rc) return rc;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   const bool in_bf16 = d->in_dtype == VITMI_BF16;
-  const bool fast_ok = gemm_fast_supported(g, in_bf16);
+  const bool fast_ok = g.batch == 1 && gemm_fast_supported(g, in_bf16);
   if (d->impl == VITMI_GEMM_FAST)
     VITMI_REQUIRE(fast_ok, VITMI_E_SHAPE, "gemm: VITMI_GEMM_FAST requested but shape/dtype/alignment unsupported (M=%lld N=%lld K=%lld)",
                   (long long)d->M, (long long)d->N, (long long)d->K);
   if (fast_ok && d->impl != VITMI_GEMM_GENERIC) return gemm_fast_launch(g, stream);
 
-  dim3 grid((unsigned)((g.N + GBN - 1) / GBN), (unsigned)((g.M + GBM - 1) / GBM));
+  dim3 grid((unsigned)((g.N + GBN - 1) / GBN), (unsigned)((g.M + GBM - 1) / GBM), (unsigned)g.batch);
   VITMI_REQUIRE(grid.y <= 65535u, VITMI_E_SHAPE, "gemm: M too large for the generic kernel grid");
   if (in_bf16) hipLaunchKernelGGL(gemm_generic_kernel<bf16>, grid, dim3(256), 0, stream, g);
   else hipLaunchKernelGGL(gemm_generic_kernel<float>, grid, dim3(256), 0, stream, g);

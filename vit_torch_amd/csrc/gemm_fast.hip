@@ -630,7 +630,7 @@ bool gemm_fast_supported(const GemmArgs& g, int in_bf16) {
   if (g.lda % 8 || g.ldb % 8 || !is_aligned(g.A, 16) || !is_aligned(g.B, 16)) return false;
   const size_t cb = e.c_bf16 ? 8 : 16;
   if (e.ldc % 4 || !is_aligned(e.C, cb)) return false;
-  if (e.C2 && (e.ldc2 % 4 || !is_aligned(e.C2, cb))) return false;
+  if (e.C2 && (e.ldc2 % 8 || !is_aligned(e.C2, 16))) return false;
   if (e.bias && !is_aligned(e.bias, 16)) return false;
   if (e.gamma && !is_aligned(e.gamma, 16)) return false;
   if (e.mode == VITMI_EPI_RESIDUAL && (e.ldr % 4 || !is_aligned(e.R, cb))) return false;

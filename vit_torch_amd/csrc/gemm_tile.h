@@ -156,6 +156,12 @@ __device__ __forceinline__ void epi_row(const EpiArgs& e, int64_t m, int64_t n, 
     }
     if (e.C2) storev<TC, W>(reinterpret_cast<TC*>(e.C2) + m * e.ldc2 + n, pre);
   } else if constexpr (MODE == VITMI_EPI_RESIDUAL) {
+    if (e.C2) {                              // un-scaled branch output, operand dtype (bf16 here)
+      float f[W];
+#pragma unroll
+      for (int i = 0; i < W; ++i) f[i] = v[i] + b[i];
+      storev<bf16, W>(reinterpret_cast<bf16*>(e.C2) + m * e.ldc2 + n, f);
+    }
 #pragma unroll
     for (int i = 0; i < W; ++i) v[i] = x[i] + gm[i] * (v[i] + b[i]);
   } else if constexpr (MODE == VITMI_EPI_DGELU) {

@@ -76,16 +76,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
                                                      const TG* g_in, TG* g_out, int64_t gstride,
                                                      TGB* __restrict__ gb_out, int64_t gbs,
                                                      float* __restrict__ part, int want_gsum,
+                                                     const float* __restrict__ gb_scale,
                                                      int64_t M, int D) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [4][D]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  f32x4 gam[LN_MAXV], dg[LN_MAXV], db[LN_MAXV], gs[LN_MAXV];
+  f32x4 gam[LN_MAXV], dg[LN_MAXV], db[LN_MAXV], gs[LN_MAXV], gsc[LN_MAXV];
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
     const int c = (i * 64 + lane) * 4;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    dg[i] = z; db[i] = z; gam[i] = z; gs[i] = z;
-    if (c < D) gam[i] = *reinterpret_cast<const f32x4*>(gamma + c);
+    const f32x4 one = {1.f, 1.f, 1.f, 1.f};
+    dg[i] = z; db[i] = z; gam[i] = z; gs[i] = z; gsc[i] = one;
+    if (c < D) {
+      gam[i] = *reinterpret_cast<const f32x4*>(gamma + c);
+      if (gb_scale) gsc[i] = *reinterpret_cast<const f32x4*>(gb_scale + c);
+    }
   }
   const float invD = 1.f / (float)D;
   for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < M; row += (int64_t)gridDim.x * 4) {
@@ -125,9 +130,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
           for (int j = 0; j < 4; ++j) o[j] += gi[j];
         }
         store4<TG>(g_out + row * gstride + c, o);
+        // the GEMM-operand copy (and its column sum) carry the LayerScale of the branch
+        // that will consume them: d(branch out) = g_out * gamma_branch
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] *= gsc[i][j];
         if (gb_out) store4<TGB>(gb_out + row * gbs + c, o);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) gs[i][j] += o[j];     // column sum of the outgoing gradient
+        for (int j = 0; j < 4; ++j) gs[i][j] += o[j];
       }
     }
   }
@@ -197,8 +206,8 @@ extern "C" int vitmi_layernorm_bwd(const void* dy, int dy_dtype, int64_t dy_stri
                                    const float* rstd, const float* gamma, const void* g_in,
                                    void* g_out, int g_dtype, int64_t g_stride, void* gb_out,
                                    int gb_dtype, int64_t gb_stride, float* dgamma, float* dbeta,
-                                   float* gsum, int64_t M, int64_t D, void* workspace,
-                                   size_t workspace_bytes, void* stream_) {
+                                   float* gsum, const float* gb_scale, int64_t M, int64_t D,
+                                   void* workspace, size_t workspace_bytes, void* stream_) {
   int rc = check_ln_common(x, x_dtype, x_stride, M, D, "layernorm_bwd");
   if (rc) return rc;
   VITMI_REQUIRE(dy && mean && rstd && gamma && g_out && dgamma && dbeta, VITMI_E_BADARG, "layernorm_bwd: null argument");
@@ -218,12 +227,14 @@ extern "C" int vitmi_layernorm_bwd(const void* dy, int dy_dtype, int64_t dy_stri
 #define LN_BWD(TDY, TX, TG, TGB)                                                               \
   hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TG, TGB>), dim3(nblk), dim3(256), lds, stream,    \
                      (const TDY*)dy, dy_stride, (const TX*)x, x_stride, mean, rstd, gamma,     \
-                     (const TG*)g_in, (TG*)g_out, g_stride, (TGB*)gb_out, gb_stride, part, gsum ? 1 : 0, M, (int)D)
+                     (const TG*)g_in, (TG*)g_out, g_stride, (TGB*)gb_out, gb_stride, part, gsum ? 1 : 0, gb_scale, M, (int)D)
   const int gbd = gb_out ? gb_dtype : dy_dtype;
   if (dy_dtype == VITMI_F32 && x_dtype == VITMI_F32 && g_dtype == VITMI_F32 && gbd == VITMI_F32) LN_BWD(float, float, float, float);
   else if (dy_dtype == VITMI_BF16 && x_dtype == VITMI_F32 && g_dtype == VITMI_F32 && gbd == VITMI_BF16) LN_BWD(bf16, float, float, bf16);
   else if (dy_dtype == VITMI_BF16 && x_dtype == VITMI_BF16 && g_dtype == VITMI_BF16 && gbd == VITMI_BF16) LN_BWD(bf16, bf16, bf16, bf16);
   else if (dy_dtype == VITMI_F32 && x_dtype == VITMI_BF16 && g_dtype == VITMI_BF16 && gbd == VITMI_F32) LN_BWD(float, bf16, bf16, float);
+  else if (dy_dtype == VITMI_F32 && x_dtype == VITMI_F32 && g_dtype == VITMI_F32 && gbd == VITMI_BF16) LN_BWD(float, float, float, bf16);
+  else if (dy_dtype == VITMI_F32 && x_dtype == VITMI_BF16 && g_dtype == VITMI_BF16 && gbd == VITMI_BF16) LN_BWD(float, bf16, bf16, bf16);
   else return vitmi_fail(VITMI_E_DTYPE, "layernorm_bwd: dtype combination (dy=%d x=%d g=%d gb=%d)", dy_dtype, x_dtype, g_dtype, gbd);
 #undef LN_BWD
   rc = vitmi_check_launch("ln_bwd_kernel");

@@ -69,7 +69,8 @@ def gemm(A, B, C_out, *, a_kmajor=True, b_kmajor=True, epilogue=EPI_STORE, bias=
     d.epilogue = epilogue
     d.C, d.ldc, d.c_dtype = C_out.data_ptr(), C_out.stride(0), dtype_code(C_out)
     if C2 is not None:
-        assert C2.dtype == C_out.dtype and tuple(C2.shape) == (M, N) and C2.stride(1) == 1
+        want = A.dtype if epilogue == EPI_RESIDUAL else C_out.dtype
+        assert C2.dtype == want and tuple(C2.shape) == (M, N) and C2.stride(1) == 1
         d.C2, d.ldc2 = C2.data_ptr(), C2.stride(0)
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
@@ -98,6 +99,29 @@ def gemm(A, B, C_out, *, a_kmajor=True, b_kmajor=True, epilogue=EPI_STORE, bias=
         ws = workspace(need, A.device)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     check(lib.vitmi_gemm(C.byref(d), _stream()), "vitmi_gemm")
+    return C_out
+
+
+def gemm_batched(A, B, C_out, *, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, batch, batch_inner,
+                 a_bs, b_bs, c_bs, a_off=0, b_off=0, c_off=0, alpha=1.0):
+    """batch independent products on strided views of A/B/C storage (element offsets/strides):
+    C_z = alpha * op(A_z) op(B_z)^T, z = zo*batch_inner + zi.  Generic MFMA kernel."""
+    _need_cuda(A, B, C_out)
+    assert A.dtype == B.dtype
+    d = GemmDesc()
+    d.M, d.N, d.K = M, N, K
+    d.A, d.lda, d.a_kmajor = A.data_ptr() + a_off * A.element_size(), lda, int(a_kmajor)
+    d.B, d.ldb, d.b_kmajor = B.data_ptr() + b_off * B.element_size(), ldb, int(b_kmajor)
+    d.in_dtype = dtype_code(A)
+    d.epilogue = EPI_STORE
+    d.C, d.ldc, d.c_dtype = C_out.data_ptr() + c_off * C_out.element_size(), ldc, dtype_code(C_out)
+    d.alpha = float(alpha)
+    d.impl = GEMM_GENERIC
+    d.batch, d.batch_inner = batch, batch_inner
+    d.a_bs[0], d.a_bs[1] = a_bs
+    d.b_bs[0], d.b_bs[1] = b_bs
+    d.c_bs[0], d.c_bs[1] = c_bs
+    check(load().vitmi_gemm(C.byref(d), _stream()), "vitmi_gemm(batched)")
     return C_out
 
 
@@ -131,8 +155,9 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps, *, M=None, D=None, x_strid
     return y
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, g_in, g_out, gb_out, dgamma, dbeta, *, gsum=None, M=None,
-                  D=None, dy_stride=None, x_stride=None, g_stride=None, gb_stride=None):
+def layernorm_bwd(dy, x, mean, rstd, gamma, g_in, g_out, gb_out, dgamma, dbeta, *, gsum=None,
+                  gb_scale=None, M=None, D=None, dy_stride=None, x_stride=None, g_stride=None,
+                  gb_stride=None):
     _need_cuda(dy, x, g_out)
     D = D or x.shape[-1]
     M = M or dy.numel() // D
@@ -146,7 +171,8 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, g_in, g_out, gb_out, dgamma, dbeta, 
         _ptr(g_in), g_out.data_ptr(), dtype_code(g_out), g_stride if g_stride is not None else D,
         _ptr(gb_out), dtype_code(gb_out) if gb_out is not None else dtype_code(dy),
         gb_stride if gb_stride is not None else D,
-        dgamma.data_ptr(), dbeta.data_ptr(), _ptr(gsum), M, D, ws.data_ptr(), ws.numel(), _stream()),
+        dgamma.data_ptr(), dbeta.data_ptr(), _ptr(gsum), _ptr(gb_scale), M, D, ws.data_ptr(), ws.numel(),
+        _stream()),
         "vitmi_layernorm_bwd")
 
 
@@ -219,3 +245,54 @@ def sgd_momentum(p, g, buf, shadow, lr, momentum, grad_scale=1.0):
     check(load().vitmi_sgd_momentum(p.data_ptr(), g.data_ptr(), buf.data_ptr(), _ptr(shadow),
                                     p.numel(), float(lr), float(momentum), float(grad_scale),
                                     _stream()), "vitmi_sgd_momentum")
+
+
+# ------------------------------------------------------------------ CaiT ops ---
+def th_softmax_fwd(S, Wl, bl, Ww, bw, P, Pm, B, H, N, Nk, ld):
+    _need_cuda(S, P, Pm)
+    check(load().vitmi_th_softmax_fwd(S.data_ptr(), Wl.data_ptr(), bl.data_ptr(), Ww.data_ptr(), bw.data_ptr(),
+                                      P.data_ptr(), Pm.data_ptr(), dtype_code(S), B, H, N, Nk, ld, _stream()),
+          "vitmi_th_softmax_fwd")
+
+
+def th_softmax_bwd(S, P, dPm, Wl, Ww, dS, dWl, dbl, dWw, dbw, B, H, N, Nk, ld):
+    _need_cuda(S, P, dPm, dS)
+    lib = load()
+    ws = workspace(lib.vitmi_th_softmax_bwd_workspace(B, H, N), S.device)
+    check(lib.vitmi_th_softmax_bwd(S.data_ptr(), P.data_ptr(), dPm.data_ptr(), Wl.data_ptr(), Ww.data_ptr(),
+                                   dS.data_ptr(), dWl.data_ptr(), dbl.data_ptr(), dWw.data_ptr(), dbw.data_ptr(),
+                                   dtype_code(S), B, H, N, Nk, ld, ws.data_ptr(), ws.numel(), _stream()),
+          "vitmi_th_softmax_bwd")
+
+
+def class_attn_fwd(q, k, v, kv_stride, out, p_save, B, H, N, hd, scale):
+    _need_cuda(q, k, v, out, p_save)
+    check(load().vitmi_class_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), kv_stride, out.data_ptr(),
+                                      p_save.data_ptr(), dtype_code(q), B, H, N, hd, float(scale), _stream()),
+          "vitmi_class_attn_fwd")
+
+
+def class_attn_bwd(q, k, v, kv_stride, dout, p_save, dq, dk, dv, dkv_stride, B, H, N, hd, scale):
+    _need_cuda(q, k, v, dout, dq, dk, dv)
+    check(load().vitmi_class_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), kv_stride, dout.data_ptr(),
+                                      p_save.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dkv_stride,
+                                      dtype_code(q), B, H, N, hd, float(scale), _stream()), "vitmi_class_attn_bwd")
+
+
+def colsum_mul(x, y, out, *, M=None, N=None, ldx=None, ldy=None):
+    _need_cuda(x, y, out)
+    N = N or x.shape[-1]
+    M = M or x.numel() // N
+    lib = load()
+    ws = workspace(lib.vitmi_colsum_mul_workspace(M, N), x.device)
+    check(lib.vitmi_colsum_mul(x.data_ptr(), dtype_code(x), ldx or N, y.data_ptr(), dtype_code(y), ldy or N,
+                               M, N, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "vitmi_colsum_mul")
+    return out
+
+
+def scale_cast(x, out, scale=None, *, M, N, ldx=None, ldo=None):
+    """out[m, :N] = cast(x[m, :N] * scale); rows at strides ldx / ldo (elements)."""
+    _need_cuda(x, out)
+    check(load().vitmi_scale_cast(x.data_ptr(), dtype_code(x), ldx or N, _ptr(scale), out.data_ptr(),
+                                  dtype_code(out), ldo or N, M, N, _stream()), "vitmi_scale_cast")
+    return out

@@ -22,6 +22,9 @@ from .vit import VisionTransformer
 class VisionModelZoo:
     archs_types = {
         "dino": ["dino_vits16", "dino_vits8", "dino_vitb16", "dino_vitb8"],
+        # models/vision_all.py:44-49 / models/cait.py:13-18
+        "cait": ["cait_M48", "cait_M36", "cait_S36", "cait_S24", "cait_S24_224", "cait_XS24", "cait_XXS24",
+                 "cait_XXS24_224", "cait_XXS36", "cait_XXS36_224"],
     }
     # name: (patch, embed_dim, depth, heads) — DINO vit_small / vit_base
     dino_cfg = {
@@ -74,6 +77,27 @@ class VisionModelZoo:
             _head = model.head
             model.head = nn.Identity()
             model.apply_head = False
+            return model, _head
+        return model
+
+    @classmethod
+    def get_model_cait(cls, arch="cait_M36", pretrained=True, image_channels=3, classifier=None,
+                       classifier_act=GELU(), return_separate=False, **model_kwargs):
+        """models/vision_all.py:184-221 (timm create_model -> models/cait.py factory)."""
+        from .cait import create_cait
+        model = create_cait(arch, pretrained=bool(pretrained), num_classes=1000,
+                            in_chans=3 if image_channels is None else image_channels, **model_kwargs)
+        if classifier is False:
+            model.head = nn.Identity()
+            model.head_dist = model.head
+        elif isinstance(classifier, (int, list)):
+            backbone_features = model.norm.weight.data.shape[-1]
+            model.head = cls.get_classifier_head(in_features=backbone_features, classifier_units=classifier,
+                                                 classifier_act=classifier_act)
+            model.head_dist = model.head
+        if return_separate:
+            _head = model.head
+            model.head = nn.Identity()
             return model, _head
         return model
 
