@@ -50,7 +50,9 @@ def test_th_softmax_fwd_bwd(ops, dt, B, H, N):
     assert_close("dS", dS[..., :N], Sr.grad, 1e-4 if dt == torch.float32 else 3e-2)
     gt = 1e-4 if dt == torch.float32 else 3e-2
     assert_close("dWl", g[0].view(H, H), prm[0].grad, gt)
-    assert_close("dbl", g[1], prm[1].grad, gt)
+    # d bl is analytically ZERO (softmax ignores a per-row constant): only rounding noise on
+    # both sides, so bound it against the scale of dWl instead of comparing noise with noise
+    assert g[1].abs().max().item() <= (1e-5 if dt == torch.float32 else 2e-2) * max(prm[0].grad.abs().max().item(), 1e-6)
     assert_close("dWw", g[2].view(H, H), prm[2].grad, gt)
     assert_close("dbw", g[3], prm[3].grad, gt)
 
@@ -126,6 +128,13 @@ TINY = dict(img_size=32, patch_size=8, embed_dim=64, depth=2, num_heads=4, mlp_r
             norm_layer=partial(nn.LayerNorm, eps=1e-6), init_scale=1e-1, depth_token_only=2, num_classes=10)
 
 
+def zero_grad_param(n):
+    """Parameters whose gradient is analytically ZERO (softmax ignores a per-row constant):
+    the talking-heads pre-softmax bias and the class-attention key bias.  Reference and build
+    both produce only rounding noise there, so they are bounded, not compared."""
+    return n.endswith("proj_l.bias") or (n.startswith("blocks_token_only") and n.endswith("attn.k.bias"))
+
+
 def make_pair(cfg, compute, residual="fp32"):
     from oracle.cait_ref import CaiT
     from oracle.vit_ref import seeded_init_
@@ -163,6 +172,9 @@ def test_cait_tiny_fp32_matches_oracle():
     worst = 0.0
     for (n, pr), (n2, pm) in zip(ref.named_parameters(), m.named_parameters()):
         assert n == n2
+        if zero_grad_param(n):              # analytically zero gradient: rounding noise only
+            assert pm.grad.abs().max().item() < 1e-6
+            continue
         worst = max(worst, assert_close(f"grad[{n}]", pm.grad, pr.grad, 3e-4))
     print(f"\ncait tiny fp32: logits rel err {e:.2e}, worst grad rel err {worst:.2e}")
 
@@ -175,6 +187,8 @@ def test_cait_tiny_bf16_close_to_oracle(residual):
     assert abs(loss.item() - lr.item()) < 2e-2
     worst = 0.0
     for (n, pr), (_, pm) in zip(ref.named_parameters(), m.named_parameters()):
+        if zero_grad_param(n):
+            continue
         gn_ref, gn = pr.grad.norm().item(), pm.grad.float().norm().item()
         rel = abs(gn - gn_ref) / max(gn_ref, 1e-12)
         worst = max(worst, rel)
@@ -202,6 +216,8 @@ def test_cait_s24_224_full_size_fp32_logits_within_1e3():
     assert abs(loss.item() - lr.item()) < 1e-3
     worst = 0.0
     for (n, pr), (_, pm) in zip(ref.named_parameters(), m.named_parameters()):
+        if zero_grad_param(n):
+            continue
         gn_ref, gn = pr.grad.norm().item(), pm.grad.norm().item()
         worst = max(worst, abs(gn - gn_ref) / max(gn_ref, 1e-12))
     assert worst < 2e-3
