@@ -185,6 +185,37 @@ int vitmi_colsum_mul(const void* x, int x_dtype, int64_t ldx, const void* y, int
                      int64_t M, int64_t N, float* out, void* workspace, size_t workspace_bytes,
                      void* stream);
 
+/* ------------------------------------------------------------- Swin ops --
+ * (Shifted-)window attention, models/swin.py:113-144 inside SwinTransformerBlock.forward
+ * :241-261.  qkv [B*L, 3*H*hd] and out/dout [B*L, H*hd] stay in TOKEN order: the cyclic
+ * shift, window_partition and window_reverse are folded into the kernels' row addressing.
+ * Bw = B * (Himg/ws) * (Wimg/ws) windows of N = ws*ws <= 64 tokens; bias [H,N,N] fp32 (the
+ * gathered relative position bias), mask [nW,N,N] fp32 or NULL (shift mask, -100/0);
+ * lse [Bw,H,N]. */
+int vitmi_win_attn_fwd(const void* qkv, void* out, float* lse, const float* bias, const float* mask,
+                       int dtype, int64_t Bw, int64_t H, int64_t N, int64_t hd,
+                       int64_t Himg, int64_t Wimg, int64_t ws, int64_t shift, float scale, void* stream);
+size_t vitmi_win_attn_bwd_workspace(int64_t Bw, int64_t H, int64_t N);
+/* dqkv (token order) and dbias [H,N,N] = sum over windows of d(score) (deterministic) */
+int vitmi_win_attn_bwd(const void* qkv, const void* dout, const float* lse, const float* bias,
+                       const float* mask, void* dqkv, float* dbias, int dtype,
+                       int64_t Bw, int64_t H, int64_t N, int64_t hd,
+                       int64_t Himg, int64_t Wimg, int64_t ws, int64_t shift, float scale,
+                       void* workspace, size_t workspace_bytes, void* stream);
+/* relative_position_bias_table[T,H] <-> bias[H,N,N] through relative_position_index[N*N]
+ * (models/swin.py:126-129): gather when (table,bias) given, gradient scatter when
+ * (dbias,dtable) given (dtable overwritten). */
+int vitmi_relpos_bias(const float* table, const int64_t* index, float* bias, const float* dbias,
+                      float* dtable, int64_t T, int64_t H, int64_t N, void* stream);
+/* PatchMerging's 2x2 gather (models/swin.py:317-323): [B,Hh*Ww,C] -> [B,Hh/2*Ww/2,4C]
+ * (inverse=1: the scatter back, i.e. its backward) */
+int vitmi_patch_merge(const void* src, void* dst, int dtype, int64_t B, int64_t Hh, int64_t Ww,
+                      int64_t C, int inverse, void* stream);
+/* AdaptiveAvgPool1d(1) over tokens (models/swin.py:584): out[B,C] fp32 = mean_l x[B,L,C]
+ * when (x,out) given; dx = dout/L when (dout,dx) given */
+int vitmi_token_mean(const void* x, float* out, const float* dout, void* dx, int dtype,
+                     int64_t B, int64_t L, int64_t C, void* stream);
+
 /* ---------------------------------------------------------- Elementwise --*/
 /* fp32 -> bf16 shadow copy of the flat parameter buffer */
 int vitmi_cast(const void* src, int src_dtype, void* dst, int dst_dtype,

@@ -130,3 +130,43 @@ def test_cait_tiny_model_matches_reference():
     loss.backward()
     for n, p in m.named_parameters():
         assert_close(f"grad[{n}]", p.grad, groups["grad"][n], 2e-5)
+
+
+# ------------------------------------------------------------------- Swin oracle ---
+def test_swin_window_attention_matches_reference():
+    from oracle.swin_ref import WindowAttention
+    top, groups = load("window_attention")
+    wa = WindowAttention(32, (7, 7), 2)
+    check_module(wa, top, groups)
+    # with a shift mask
+    wa.zero_grad()
+    x = top["x"].clone().requires_grad_(True)
+    y = wa(x, top["mask"])
+    assert_close("y_masked", y, top["y_masked"], 2e-6)
+    y.backward(top["dy"])
+    assert_close("dx_masked", x.grad, top["dx_masked"], 1e-5)
+    for n, p in wa.named_parameters():
+        assert_close(f"grad_masked[{n}]", p.grad, groups["grad_masked"][n], 1e-5)
+
+
+def test_swin_patch_merging_matches_reference():
+    from oracle.swin_ref import PatchMerging
+    top, groups = load("patch_merging")
+    check_module(PatchMerging((8, 8), 16), top, groups)
+
+
+def test_swin_tiny_model_matches_reference():
+    import torch.nn.functional as F
+    from oracle.swin_ref import SwinTransformer
+    top, groups = load("swin_tiny")
+    m = SwinTransformer(img_size=56, patch_size=4, in_chans=3, num_classes=10, embed_dim=32, depths=[2, 2],
+                        num_heads=[2, 4], window_size=7, drop_path_rate=0.0)
+    res = m.load_state_dict(groups["state"], strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    logits = m(top["x"])
+    assert_close("logits", logits, top["logits"], 2e-6)
+    loss = F.cross_entropy(logits, top["labels"])
+    assert abs(loss.item() - top["loss"].item()) < 1e-6
+    loss.backward()
+    for n, p in m.named_parameters():
+        assert_close(f"grad[{n}]", p.grad, groups["grad"][n], 2e-5)

@@ -1,0 +1,182 @@
+"""Swin on the HIP path against the CPU oracle (oracle/swin_ref.py, pinned to the reference by
+tests/golden/{window_attention,patch_merging,swin_tiny}.npz) and the Swin ops against PyTorch."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import assert_close, bf16_round
+
+pytestmark = pytest.mark.gpu
+
+
+def gen(shape, seed, scale=1.0):
+    return torch.randn(shape, generator=torch.Generator("cpu").manual_seed(seed)) * scale
+
+
+@pytest.fixture(scope="module")
+def ops(lib):
+    from vit_torch_amd import ops as _o
+    return _o
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,Hh,Ww,ws,shift,H,hd", [(2, 14, 14, 7, 0, 2, 16), (2, 14, 14, 7, 3, 3, 32), (1, 8, 8, 4, 2, 2, 8), (3, 7, 7, 7, 0, 4, 32)])
+def test_window_attention_in_token_order(ops, dt, B, Hh, Ww, ws, shift, H, hd):
+    """roll -> window_partition -> attention(+bias,+mask) -> window_reverse -> roll back
+    (models/swin.py:241-261) against the kernels that do it all through addressing."""
+    from oracle.swin_ref import shift_attn_mask, window_partition, window_reverse
+    C, N, L = H * hd, ws * ws, Hh * Ww
+    scale = hd ** -0.5
+    rd = bf16_round if dt == torch.bfloat16 else (lambda t: t)
+    qkv = rd(gen((B, L, 3 * C), 1))
+    do = rd(gen((B, L, C), 2))
+    bias = gen((H, N, N), 3, 0.5)
+    mask = shift_attn_mask(Hh, Ww, ws, shift) if shift > 0 else None
+    qr = qkv.clone().requires_grad_(True)
+    br = bias.clone().requires_grad_(True)
+    x = qr.view(B, Hh, Ww, 3 * C)
+    if shift:
+        x = torch.roll(x, shifts=(-shift, -shift), dims=(1, 2))
+    xw = window_partition(x, ws).view(-1, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = xw[0] * scale, xw[1], xw[2]
+    attn = q @ k.transpose(-2, -1) + br.unsqueeze(0)
+    if mask is not None:
+        nW = mask.shape[0]
+        attn = (attn.view(B, nW, H, N, N) + mask.unsqueeze(1).unsqueeze(0)).view(-1, H, N, N)
+    o = (attn.softmax(-1) @ v).transpose(1, 2).reshape(-1, ws, ws, C)
+    o = window_reverse(o, ws, Hh, Ww)
+    if shift:
+        o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
+    o = o.reshape(B, L, C)
+    o.backward(do)
+    Bw = B * (Hh // ws) * (Ww // ws)
+    Q = qkv.to("cuda", dt).contiguous()
+    O = torch.empty((B, L, C), device="cuda", dtype=dt)
+    lse = torch.empty(Bw * H * N, device="cuda")
+    bd = bias.cuda().contiguous()
+    md = mask.cuda().contiguous() if mask is not None else None
+    ops.win_attn_fwd(Q, O, lse, bd, md, Bw, H, N, hd, Hh, Ww, ws, shift, scale)
+    tol = 2e-5 if dt == torch.float32 else 1.5e-2
+    assert_close("win.out", O, o.detach(), tol)
+    dqkv = torch.full((B, L, 3 * C), float("nan"), device="cuda").to(dt)
+    dbias = torch.empty(H * N * N, device="cuda")
+    ops.win_attn_bwd(Q, do.to("cuda", dt).contiguous(), lse, bd, md, dqkv, dbias, Bw, H, N, hd, Hh, Ww, ws, shift, scale)
+    bt = 5e-5 if dt == torch.float32 else 2.5e-2
+    assert_close("win.dqkv", dqkv, qr.grad, bt)
+    assert_close("win.dbias", dbias.view(H, N, N), br.grad, bt)
+
+
+def test_relpos_bias_gather_scatter(ops):
+    from oracle.swin_ref import relative_position_index
+    ws, H = 7, 3
+    N, T = ws * ws, (2 * ws - 1) ** 2
+    table = gen((T, H), 1)
+    idx = relative_position_index(ws)
+    want = table[idx.view(-1)].view(N, N, H).permute(2, 0, 1)
+    bias = torch.empty(H * N * N, device="cuda")
+    ops.relpos_bias_gather(table.cuda(), idx.cuda(), bias, T, H, N)
+    assert torch.equal(bias.view(H, N, N).cpu(), want)
+    db = gen((H, N, N), 2)
+    tr = table.clone().requires_grad_(True)
+    tr[idx.view(-1)].view(N, N, H).permute(2, 0, 1).backward(db)
+    dt = torch.empty((T, H), device="cuda")
+    ops.relpos_bias_scatter(db.cuda().contiguous(), idx.cuda(), dt, T, H, N)
+    assert_close("dtable", dt, tr.grad, 1e-6)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_patch_merge_and_token_mean(ops, dt):
+    B, Hh, Ww, C = 2, 6, 8, 16
+    x = gen((B, Hh * Ww, C), 1).to(dt)
+    xv = x.view(B, Hh, Ww, C)
+    want = torch.cat([xv[:, 0::2, 0::2], xv[:, 1::2, 0::2], xv[:, 0::2, 1::2], xv[:, 1::2, 1::2]], -1).reshape(B, -1, 4 * C)
+    out = torch.empty((B, Hh * Ww // 4, 4 * C), device="cuda", dtype=dt)
+    ops.patch_merge(x.cuda(), out, B, Hh, Ww, C)
+    assert torch.equal(out.cpu(), want)
+    back = torch.empty((B, Hh * Ww, C), device="cuda", dtype=dt)
+    ops.patch_merge(out, back, B, Hh, Ww, C, inverse=True)
+    assert torch.equal(back.cpu(), x)
+    m = torch.empty((B, C), device="cuda")
+    ops.token_mean_fwd(x.cuda(), m, B, Hh * Ww, C)
+    assert_close("mean", m, x.float().mean(1), 1e-5)
+    dx = torch.empty((B, Hh * Ww, C), device="cuda", dtype=dt)
+    ops.token_mean_bwd(m, dx, B, Hh * Ww, C)
+    assert_close("dmean", dx, (m.cpu() / (Hh * Ww)).unsqueeze(1).expand(B, Hh * Ww, C), 1e-2 if dt == torch.bfloat16 else 1e-6)
+
+
+TINY = dict(img_size=56, patch_size=4, in_chans=3, num_classes=10, embed_dim=32, depths=[2, 2], num_heads=[2, 4],
+            window_size=7, drop_path_rate=0.0)
+
+
+def make_pair(cfg, compute, residual="fp32"):
+    from oracle.swin_ref import SwinTransformer as Ref
+    from oracle.vit_ref import seeded_init_
+    from vit_torch_amd import SwinTransformer
+    ref = Ref(**cfg)
+    seeded_init_(ref, 7)
+    m = SwinTransformer(**cfg, compute_dtype=compute, residual_dtype=residual)
+    res = m.load_state_dict(ref.state_dict(), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    return ref, m.cuda()
+
+
+def step(ref, m, B, S):
+    from vit_torch_amd import CrossEntropyLoss
+    g = torch.Generator("cpu").manual_seed(0)
+    x, y = torch.randn(B, 3, S, S, generator=g), torch.randint(0, 10, (B,), generator=g)
+    lo = ref(x)
+    lr = F.cross_entropy(lo, y)
+    ref.zero_grad(); lr.backward()
+    out = m(x.cuda())
+    loss = CrossEntropyLoss()(out, y.cuda())
+    m.zero_grad(); loss.backward()
+    return lo.detach(), lr.detach(), out.detach(), loss.detach()
+
+
+def test_swin_tiny_fp32_matches_oracle():
+    ref, m = make_pair(TINY, "fp32")
+    lo, lr, out, loss = step(ref, m, 3, 56)
+    e = assert_close("logits", out, lo, 1e-4)
+    assert abs(loss.item() - lr.item()) < 1e-4
+    worst = 0.0
+    for (n, pr), (n2, pm) in zip(ref.named_parameters(), m.named_parameters()):
+        assert n == n2
+        worst = max(worst, assert_close(f"grad[{n}]", pm.grad, pr.grad, 3e-4))
+    print(f"\nswin tiny fp32: logits rel err {e:.2e}, worst grad rel err {worst:.2e}")
+
+
+@pytest.mark.parametrize("residual", ["fp32", "bf16"])
+def test_swin_tiny_bf16_close_to_oracle(residual):
+    ref, m = make_pair(TINY, "bf16", residual)
+    lo, lr, out, loss = step(ref, m, 4, 56)
+    e = assert_close("logits", out, lo, 3e-2)
+    assert abs(loss.item() - lr.item()) < 2e-2
+    worst = 0.0
+    for (n, pr), (_, pm) in zip(ref.named_parameters(), m.named_parameters()):
+        gn_ref, gn = pr.grad.norm().item(), pm.grad.float().norm().item()
+        rel = abs(gn - gn_ref) / max(gn_ref, 1e-12)
+        worst = max(worst, rel)
+        assert rel < 8e-2, f"grad-norm[{n}]: {gn:.4g} vs {gn_ref:.4g}"
+    print(f"\nswin tiny bf16 (residual {residual}): logits rel err {e:.2e}, worst grad-norm rel err {worst:.2e}")
+
+
+def test_swin_t_full_size_fp32_logits_within_1e3():
+    """BASELINE config 5 architecture (Swin-T, drop-path 0), batch 2, parity mode."""
+    from oracle import swin_ref
+    from oracle.vit_ref import seeded_init_
+    from vit_torch_amd import VisionModelZoo
+    ref = swin_ref.build("swin_tiny_patch4_window7_224", num_classes=10, drop_path_rate=0.0)
+    seeded_init_(ref, 9)
+    m = VisionModelZoo.get_model("swin_tiny_patch4_window7_224", pretrained=False, classifier=None,
+                                 drop_path_rate=0.0, num_classes=10, compute_dtype="fp32")
+    m.load_state_dict(ref.state_dict(), strict=True)
+    m = m.cuda()
+    lo, lr, out, loss = step(ref, m, 2, 224)
+    e = assert_close("swin-T logits", out, lo, 1e-3)
+    assert abs(loss.item() - lr.item()) < 1e-3
+    worst = 0.0
+    for (n, pr), (_, pm) in zip(ref.named_parameters(), m.named_parameters()):
+        gn_ref, gn = pr.grad.norm().item(), pm.grad.norm().item()
+        worst = max(worst, abs(gn - gn_ref) / max(gn_ref, 1e-12))
+    assert worst < 2e-3
+    print(f"\nswin-T fp32: logits rel err {e:.2e}, loss diff {abs(loss.item()-lr.item()):.2e}, worst grad-norm rel {worst:.2e}")

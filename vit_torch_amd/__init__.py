@@ -5,5 +5,6 @@ from .optim import FusedSGD  # noqa: F401
 from .vision_all import VisionModelZoo  # noqa: F401
 from .vit import VisionTransformer  # noqa: F401
 from .cait import cait_models  # noqa: F401
+from .swin import SwinTransformer  # noqa: F401
 
 __all__ = ["VisionModelZoo", "VisionTransformer", "CrossEntropyLoss", "FusedSGD", "VitmiError"]

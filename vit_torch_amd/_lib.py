@@ -64,6 +64,14 @@ SIGNATURES = {
                                        c_i64, c_i64, c_i64, c_i64, c_f32, c_vp]),
     "vitmi_colsum_mul_workspace": (c_sz, [c_i64, c_i64]),
     "vitmi_colsum_mul": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, C.c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_sz, c_vp]),
+    "vitmi_win_attn_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
+                                     c_i64, c_i64, c_f32, c_vp]),
+    "vitmi_win_attn_bwd_workspace": (c_sz, [c_i64, c_i64, c_i64]),
+    "vitmi_win_attn_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_i64,
+                                     c_i64, c_i64, c_i64, c_i64, c_f32, c_vp, c_sz, c_vp]),
+    "vitmi_relpos_bias": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]),
+    "vitmi_patch_merge": (C.c_int, [c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_i64, C.c_int, c_vp]),
+    "vitmi_token_mean": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_vp]),
     "vitmi_cast": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, c_i64, c_vp]),
     "vitmi_scale_cast": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_vp]),
     "vitmi_patchify": (C.c_int, [c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, C.c_int, c_i64, c_i64,

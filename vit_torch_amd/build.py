@@ -30,6 +30,7 @@ SOURCES = [
     "attention.hip",
     "attention_f32.hip",
     "cait_ops.hip",
+    "swin_ops.hip",
 ]
 HEADERS = ["common.h", "epilogue.h", "gemm_tile.h", "../../include/vitmi.h"]
 

@@ -1,0 +1,351 @@
+// Swin-specific kernels:
+//  * (shifted-)window attention, models/swin.py:113-144 + :241-261: the cyclic shift
+//    (torch.roll), window_partition and window_reverse are NOT materialised — every row
+//    access goes through the window->token map below, so qkv, the attention output and
+//    their gradients stay in token order and the reference's four permute/roll copies per
+//    block disappear.  Relative-position bias [H,N,N] and the -100 shift mask [nW,N,N] are
+//    added to the scores in registers.
+//  * relative-position-bias gather / gradient scatter (:126-129), PatchMerging gather /
+//    scatter (:317-323), token mean (AdaptiveAvgPool1d, :584).
+// First version of this row: fp32 vector math for both activation dtypes (N = 49 tokens and
+// hd = 32 leave the MFMA shapes mostly empty; an MFMA version is the next step).
+// One workgroup = one (window, head); 4 waves; window tokens N <= 64, hd <= 64.
+#include "common.h"
+
+namespace {
+
+struct WinGeom { int Himg, Wimg, ws, shift, nWx, nW; };
+
+// global token row of local position i of window bw (bw = image * nW + window)
+__device__ __forceinline__ int64_t win_token(const WinGeom& g, int64_t bw, int i) {
+  const int64_t b = bw / g.nW;
+  const int w = (int)(bw % g.nW);
+  const int wy = w / g.nWx, wx = w % g.nWx;
+  int y = wy * g.ws + i / g.ws + g.shift;
+  int x = wx * g.ws + i % g.ws + g.shift;
+  if (y >= g.Himg) y -= g.Himg;
+  if (x >= g.Wimg) x -= g.Wimg;
+  return b * (int64_t)g.Himg * g.Wimg + (int64_t)y * g.Wimg + x;
+}
+
+// stage rows [N][hd] of one head (through the window map) into LDS, row stride hd+1
+template <typename T>
+__device__ __forceinline__ void stage_win(float* lds, const T* base, int64_t ts, const WinGeom& g,
+                                          int64_t bw, int N, int hd, int tid) {
+  for (int idx = tid; idx < 64 * hd; idx += 256) {
+    const int r = idx / hd, d = idx % hd;
+    lds[r * (hd + 1) + d] = r < N ? to_f32(base[win_token(g, bw, r) * ts + d]) : 0.f;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void win_attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+                                                          float* __restrict__ lse, const float* __restrict__ bias,
+                                                          const float* __restrict__ mask, WinGeom g, int H, int N,
+                                                          int hd, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Qs = sm;
+  float* Ks = Qs + 64 * (hd + 1);
+  float* Vs = Ks + 64 * (hd + 1);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t bw = blockIdx.x;
+  const int h = blockIdx.y;
+  const int64_t ts = (int64_t)3 * H * hd;
+  stage_win(Qs, qkv + h * hd, ts, g, bw, N, hd, tid);
+  stage_win(Ks, qkv + (H + h) * hd, ts, g, bw, N, hd, tid);
+  stage_win(Vs, qkv + (2 * H + h) * hd, ts, g, bw, N, hd, tid);
+  __syncthreads();
+  const float* mrow = mask ? mask + (bw % g.nW) * (int64_t)N * N : nullptr;
+  for (int i = w; i < N; i += 4) {
+    float s = -INFINITY;
+    if (lane < N) {
+      s = 0.f;
+      for (int d = 0; d < hd; ++d) s = fmaf(Qs[i * (hd + 1) + d] * scale, Ks[lane * (hd + 1) + d], s);
+      s += bias[((int64_t)h * N + i) * N + lane];
+      if (mrow) s += mrow[i * N + lane];
+    }
+    const float mx = wave_max(s);
+    const float p = expf(s - mx);
+    const float sum = wave_sum(p);
+    float acc = 0.f;
+    const int dl = lane < hd ? lane : 0;
+    for (int j = 0; j < N; ++j) acc = fmaf(__shfl(p, j), Vs[j * (hd + 1) + dl], acc);
+    const int64_t tok = win_token(g, bw, i);
+    if (lane < hd) out[tok * H * hd + h * hd + lane] = from_f32<T>(acc / sum);
+    if (lane == 0) lse[(bw * H + h) * N + i] = mx + logf(sum);
+  }
+}
+
+// dQ + delta + dBias (per-window partial): wave per query row
+template <typename T>
+__global__ __launch_bounds__(256) void win_attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+                                                             const float* __restrict__ lse, const float* __restrict__ bias,
+                                                             const float* __restrict__ mask, T* __restrict__ dqkv,
+                                                             float* __restrict__ delta, float* __restrict__ dbias_part,
+                                                             WinGeom g, int H, int N, int hd, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Qs = sm;
+  float* Ks = Qs + 64 * (hd + 1);
+  float* Vs = Ks + 64 * (hd + 1);
+  float* dOs = Vs + 64 * (hd + 1);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t bw = blockIdx.x;
+  const int h = blockIdx.y;
+  const int64_t ts = (int64_t)3 * H * hd, os = (int64_t)H * hd;
+  stage_win(Qs, qkv + h * hd, ts, g, bw, N, hd, tid);
+  stage_win(Ks, qkv + (H + h) * hd, ts, g, bw, N, hd, tid);
+  stage_win(Vs, qkv + (2 * H + h) * hd, ts, g, bw, N, hd, tid);
+  stage_win(dOs, dout + h * hd, os, g, bw, N, hd, tid);
+  __syncthreads();
+  const float* mrow = mask ? mask + (bw % g.nW) * (int64_t)N * N : nullptr;
+  for (int i = w; i < N; i += 4) {
+    float s = 0.f, dp = 0.f, p = 0.f;
+    if (lane < N) {
+      for (int d = 0; d < hd; ++d) {
+        s = fmaf(Qs[i * (hd + 1) + d] * scale, Ks[lane * (hd + 1) + d], s);
+        dp = fmaf(dOs[i * (hd + 1) + d], Vs[lane * (hd + 1) + d], dp);
+      }
+      s += bias[((int64_t)h * N + i) * N + lane];
+      if (mrow) s += mrow[i * N + lane];
+      p = expf(s - lse[(bw * H + h) * N + i]);
+    }
+    const float del = wave_sum(p * dp);
+    const float ds = p * (dp - del);
+    if (lane < N) dbias_part[((bw * H + h) * N + i) * N + lane] = ds;
+    if (lane == 0) delta[(bw * H + h) * N + i] = del;
+    float acc = 0.f;
+    const int dl = lane < hd ? lane : 0;
+    for (int j = 0; j < N; ++j) acc = fmaf(__shfl(ds, j), Ks[j * (hd + 1) + dl], acc);
+    if (lane < hd) dqkv[win_token(g, bw, i) * ts + h * hd + lane] = from_f32<T>(acc * scale);
+  }
+}
+
+// dK, dV: wave per key row, lanes = queries
+template <typename T>
+__global__ __launch_bounds__(256) void win_attn_bwd_dkdv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               const float* __restrict__ bias, const float* __restrict__ mask,
+                                                               T* __restrict__ dqkv, WinGeom g, int H, int N, int hd,
+                                                               float scale) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Qs = sm;
+  float* Ks = Qs + 64 * (hd + 1);
+  float* Vs = Ks + 64 * (hd + 1);
+  float* dOs = Vs + 64 * (hd + 1);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t bw = blockIdx.x;
+  const int h = blockIdx.y;
+  const int64_t ts = (int64_t)3 * H * hd, os = (int64_t)H * hd;
+  stage_win(Qs, qkv + h * hd, ts, g, bw, N, hd, tid);
+  stage_win(Ks, qkv + (H + h) * hd, ts, g, bw, N, hd, tid);
+  stage_win(Vs, qkv + (2 * H + h) * hd, ts, g, bw, N, hd, tid);
+  stage_win(dOs, dout + h * hd, os, g, bw, N, hd, tid);
+  __syncthreads();
+  const float* mrow = mask ? mask + (bw % g.nW) * (int64_t)N * N : nullptr;
+  for (int j = w; j < N; j += 4) {
+    float p = 0.f, ds = 0.f;
+    if (lane < N) {                                  // lane = query i
+      float s = 0.f, dp = 0.f;
+      for (int d = 0; d < hd; ++d) {
+        s = fmaf(Qs[lane * (hd + 1) + d] * scale, Ks[j * (hd + 1) + d], s);
+        dp = fmaf(dOs[lane * (hd + 1) + d], Vs[j * (hd + 1) + d], dp);
+      }
+      s += bias[((int64_t)h * N + lane) * N + j];
+      if (mrow) s += mrow[lane * N + j];
+      p = expf(s - lse[(bw * H + h) * N + lane]);
+      ds = p * (dp - delta[(bw * H + h) * N + lane]);
+    }
+    float ak = 0.f, av = 0.f;
+    const int dl = lane < hd ? lane : 0;
+    for (int i = 0; i < N; ++i) {
+      ak = fmaf(__shfl(ds, i), Qs[i * (hd + 1) + dl], ak);
+      av = fmaf(__shfl(p, i), dOs[i * (hd + 1) + dl], av);
+    }
+    if (lane < hd) {
+      T* row = dqkv + win_token(g, bw, j) * ts + h * hd + lane;
+      row[H * hd] = from_f32<T>(ak * scale);
+      row[2 * H * hd] = from_f32<T>(av);
+    }
+  }
+}
+
+// bias[h][i][j] = table[index[i*N + j]][h]
+__global__ void relpos_gather_kernel(const float* __restrict__ table, const int64_t* __restrict__ index,
+                                     float* __restrict__ bias, int H, int NN) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= H * NN) return;
+  const int h = t / NN, ij = t % NN;
+  bias[t] = table[index[ij] * H + h];
+}
+// dtable[t][h] = sum_{ij: index[ij]==t} dbias[h][ij]   (deterministic: one thread per entry)
+__global__ void relpos_scatter_kernel(const float* __restrict__ dbias, const int64_t* __restrict__ index,
+                                      float* __restrict__ dtable, int T, int H, int NN) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= T * H) return;
+  const int t = e / H, h = e % H;
+  float s = 0.f;
+  for (int ij = 0; ij < NN; ++ij)
+    if (index[ij] == t) s += dbias[(int64_t)h * NN + ij];
+  dtable[e] = s;
+}
+
+// PatchMerging gather (inverse = 0): out[b,(i,j), k*C + c] = x[b,(2i+dy_k, 2j+dx_k), c],
+// k = 0..3 <-> (dy,dx) = (0,0),(1,0),(0,1),(1,1); inverse = 1 scatters back (a permutation)
+template <typename T>
+__global__ void patch_merge_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t B, int Hh, int Ww, int C,
+                                   int inverse) {
+  const int c4 = C / 4;
+  const int64_t total = B * Hh * Ww * c4;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int cq = (int)(idx % c4);
+    int64_t t = idx / c4;
+    const int x = (int)(t % Ww); t /= Ww;
+    const int y = (int)(t % Hh);
+    const int64_t b = t / Hh;
+    const int k = (y & 1) + 2 * (x & 1);
+    const int64_t tok_full = (b * Hh + y) * Ww + x;
+    const int64_t tok_half = (b * (Hh / 2) + (y >> 1)) * (Ww / 2) + (x >> 1);
+    const T* s = inverse ? src + tok_half * 4 * C + k * C + cq * 4 : src + tok_full * C + cq * 4;
+    T* d = inverse ? dst + tok_full * C + cq * 4 : dst + tok_half * 4 * C + k * C + cq * 4;
+    store4<T>(d, load4<T>(s));
+  }
+}
+
+// out[b][c] = mean_l x[b][l][c]  /  dx[b][l][c] = dout[b][c] / L
+template <typename T>
+__global__ void token_mean_fwd_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t B, int L, int C) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * C) return;
+  const int64_t b = idx / C;
+  const int c = (int)(idx % C);
+  float s = 0.f;
+  for (int l = 0; l < L; ++l) s += to_f32(x[(b * L + l) * C + c]);
+  out[idx] = s / (float)L;
+}
+template <typename T>
+__global__ void token_mean_bwd_kernel(const float* __restrict__ dout, T* __restrict__ dx, int64_t B, int L, int C) {
+  const int64_t total = B * L * C;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % C);
+    const int64_t b = idx / ((int64_t)L * C);
+    dx[idx] = from_f32<T>(dout[b * C + c] / (float)L);
+  }
+}
+
+}  // namespace
+
+static int win_check(int64_t Bw, int64_t H, int64_t N, int64_t hd, int64_t Himg, int64_t Wimg, int64_t ws, int64_t shift, const char* who) {
+  VITMI_REQUIRE(Bw > 0 && H > 0 && H <= 65535, VITMI_E_BADARG, "%s: bad batch / heads", who);
+  VITMI_REQUIRE(N == ws * ws && N <= 64 && hd >= 1 && hd <= 64, VITMI_E_SHAPE, "%s: window tokens %lld (<=64) / head dim %lld (<=64)", who, (long long)N, (long long)hd);
+  VITMI_REQUIRE(Himg % ws == 0 && Wimg % ws == 0 && shift >= 0 && shift < ws, VITMI_E_SHAPE, "%s: resolution %lldx%lld not divisible by window %lld or bad shift", who, (long long)Himg, (long long)Wimg, (long long)ws);
+  VITMI_REQUIRE(Bw % ((Himg / ws) * (Wimg / ws)) == 0, VITMI_E_SHAPE, "%s: window count not a multiple of windows per image", who);
+  return 0;
+}
+
+extern "C" int vitmi_win_attn_fwd(const void* qkv, void* out, float* lse, const float* bias, const float* mask,
+                                  int dtype, int64_t Bw, int64_t H, int64_t N, int64_t hd, int64_t Himg,
+                                  int64_t Wimg, int64_t ws, int64_t shift, float scale, void* stream_) {
+  VITMI_REQUIRE(qkv && out && lse && bias, VITMI_E_BADARG, "win_attn_fwd: null argument");
+  int rc = win_check(Bw, H, N, hd, Himg, Wimg, ws, shift, "win_attn_fwd");
+  if (rc) return rc;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  WinGeom g{(int)Himg, (int)Wimg, (int)ws, (int)shift, (int)(Wimg / ws), (int)((Himg / ws) * (Wimg / ws))};
+  dim3 grid((unsigned)Bw, (unsigned)H);
+  const size_t lds = 3 * 64 * (hd + 1) * sizeof(float);
+  if (dtype == VITMI_BF16)
+    hipLaunchKernelGGL((win_attn_fwd_kernel<bf16>), grid, dim3(256), lds, stream, (const bf16*)qkv, (bf16*)out, lse, bias, mask, g, (int)H, (int)N, (int)hd, scale);
+  else if (dtype == VITMI_F32)
+    hipLaunchKernelGGL((win_attn_fwd_kernel<float>), grid, dim3(256), lds, stream, (const float*)qkv, (float*)out, lse, bias, mask, g, (int)H, (int)N, (int)hd, scale);
+  else return vitmi_fail(VITMI_E_DTYPE, "win_attn_fwd: bad dtype");
+  return vitmi_check_launch("win_attn_fwd_kernel");
+}
+
+extern "C" size_t vitmi_win_attn_bwd_workspace(int64_t Bw, int64_t H, int64_t N) {
+  return (size_t)(Bw * H * N) * sizeof(float) + (size_t)(Bw * H * N * N) * sizeof(float);
+}
+
+// dbias [H,N,N] fp32 (overwritten) = sum over windows of d(score)
+extern "C" int vitmi_win_attn_bwd(const void* qkv, const void* dout, const float* lse, const float* bias,
+                                  const float* mask, void* dqkv, float* dbias, int dtype, int64_t Bw, int64_t H,
+                                  int64_t N, int64_t hd, int64_t Himg, int64_t Wimg, int64_t ws, int64_t shift,
+                                  float scale, void* workspace, size_t workspace_bytes, void* stream_) {
+  VITMI_REQUIRE(qkv && dout && lse && bias && dqkv && dbias, VITMI_E_BADARG, "win_attn_bwd: null argument");
+  int rc = win_check(Bw, H, N, hd, Himg, Wimg, ws, shift, "win_attn_bwd");
+  if (rc) return rc;
+  VITMI_REQUIRE(workspace && workspace_bytes >= vitmi_win_attn_bwd_workspace(Bw, H, N) && is_aligned(workspace, 16), VITMI_E_WORKSPACE, "win_attn_bwd: workspace too small");
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  WinGeom g{(int)Himg, (int)Wimg, (int)ws, (int)shift, (int)(Wimg / ws), (int)((Himg / ws) * (Wimg / ws))};
+  float* delta = reinterpret_cast<float*>(workspace);
+  float* part = delta + Bw * H * N;
+  dim3 grid((unsigned)Bw, (unsigned)H);
+  const size_t lds = 4 * 64 * (hd + 1) * sizeof(float);
+  if (dtype == VITMI_BF16) {
+    hipLaunchKernelGGL((win_attn_bwd_dq_kernel<bf16>), grid, dim3(256), lds, stream, (const bf16*)qkv, (const bf16*)dout, lse, bias, mask, (bf16*)dqkv, delta, part, g, (int)H, (int)N, (int)hd, scale);
+    if ((rc = vitmi_check_launch("win_attn_bwd_dq_kernel"))) return rc;
+    hipLaunchKernelGGL((win_attn_bwd_dkdv_kernel<bf16>), grid, dim3(256), lds, stream, (const bf16*)qkv, (const bf16*)dout, lse, delta, bias, mask, (bf16*)dqkv, g, (int)H, (int)N, (int)hd, scale);
+  } else if (dtype == VITMI_F32) {
+    hipLaunchKernelGGL((win_attn_bwd_dq_kernel<float>), grid, dim3(256), lds, stream, (const float*)qkv, (const float*)dout, lse, bias, mask, (float*)dqkv, delta, part, g, (int)H, (int)N, (int)hd, scale);
+    if ((rc = vitmi_check_launch("win_attn_bwd_dq_kernel"))) return rc;
+    hipLaunchKernelGGL((win_attn_bwd_dkdv_kernel<float>), grid, dim3(256), lds, stream, (const float*)qkv, (const float*)dout, lse, delta, bias, mask, (float*)dqkv, g, (int)H, (int)N, (int)hd, scale);
+  } else return vitmi_fail(VITMI_E_DTYPE, "win_attn_bwd: bad dtype");
+  if ((rc = vitmi_check_launch("win_attn_bwd_dkdv_kernel"))) return rc;
+  // deterministic reduction of the per-window d(score) tiles: rows = windows, cols = H*N*N
+  return vitmi_reduce_rows(part, (int)Bw, H * N * N, H * N * N, dbias, stream);
+}
+
+extern "C" int vitmi_relpos_bias(const float* table, const int64_t* index, float* bias, const float* dbias,
+                                 float* dtable, int64_t T, int64_t H, int64_t N, void* stream_) {
+  VITMI_REQUIRE(index && T > 0 && H > 0 && N > 0, VITMI_E_BADARG, "relpos_bias: bad argument");
+  VITMI_REQUIRE((table && bias) || (dbias && dtable), VITMI_E_BADARG, "relpos_bias: need (table,bias) and/or (dbias,dtable)");
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const int NN = (int)(N * N);
+  if (table && bias) {
+    hipLaunchKernelGGL(relpos_gather_kernel, dim3((unsigned)((H * NN + 255) / 256)), dim3(256), 0, stream, table, index, bias, (int)H, NN);
+    int rc = vitmi_check_launch("relpos_gather_kernel");
+    if (rc) return rc;
+  }
+  if (dbias && dtable) {
+    hipLaunchKernelGGL(relpos_scatter_kernel, dim3((unsigned)((T * H + 255) / 256)), dim3(256), 0, stream, dbias, index, dtable, (int)T, (int)H, NN);
+    return vitmi_check_launch("relpos_scatter_kernel");
+  }
+  return 0;
+}
+
+extern "C" int vitmi_patch_merge(const void* src, void* dst, int dtype, int64_t B, int64_t Hh, int64_t Ww, int64_t C,
+                                 int inverse, void* stream_) {
+  VITMI_REQUIRE(src && dst && B > 0 && Hh > 0 && Ww > 0 && C > 0, VITMI_E_BADARG, "patch_merge: bad argument");
+  VITMI_REQUIRE(Hh % 2 == 0 && Ww % 2 == 0 && C % 4 == 0, VITMI_E_SHAPE, "patch_merge: H, W must be even and C a multiple of 4");
+  VITMI_REQUIRE(is_aligned(src, 4 * dtype_size(dtype)) && is_aligned(dst, 4 * dtype_size(dtype)), VITMI_E_ALIGN, "patch_merge: alignment");
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  int64_t blocks = (B * Hh * Ww * (C / 4) + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (dtype == VITMI_BF16)
+    hipLaunchKernelGGL((patch_merge_kernel<bf16>), dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16*)src, (bf16*)dst, B, (int)Hh, (int)Ww, (int)C, inverse);
+  else if (dtype == VITMI_F32)
+    hipLaunchKernelGGL((patch_merge_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)src, (float*)dst, B, (int)Hh, (int)Ww, (int)C, inverse);
+  else return vitmi_fail(VITMI_E_DTYPE, "patch_merge: bad dtype");
+  return vitmi_check_launch("patch_merge_kernel");
+}
+
+extern "C" int vitmi_token_mean(const void* x, float* out, const float* dout, void* dx, int dtype, int64_t B,
+                                int64_t L, int64_t C, void* stream_) {
+  VITMI_REQUIRE(B > 0 && L > 0 && C > 0 && ((x && out) || (dout && dx)), VITMI_E_BADARG, "token_mean: bad argument");
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (x && out) {
+    dim3 grid((unsigned)((B * C + 255) / 256));
+    if (dtype == VITMI_BF16) hipLaunchKernelGGL((token_mean_fwd_kernel<bf16>), grid, dim3(256), 0, stream, (const bf16*)x, out, B, (int)L, (int)C);
+    else if (dtype == VITMI_F32) hipLaunchKernelGGL((token_mean_fwd_kernel<float>), grid, dim3(256), 0, stream, (const float*)x, out, B, (int)L, (int)C);
+    else return vitmi_fail(VITMI_E_DTYPE, "token_mean: bad dtype");
+    int rc = vitmi_check_launch("token_mean_fwd_kernel");
+    if (rc) return rc;
+  }
+  if (dout && dx) {
+    int64_t blocks = (B * L * C + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (dtype == VITMI_BF16) hipLaunchKernelGGL((token_mean_bwd_kernel<bf16>), dim3((unsigned)blocks), dim3(256), 0, stream, dout, (bf16*)dx, B, (int)L, (int)C);
+    else if (dtype == VITMI_F32) hipLaunchKernelGGL((token_mean_bwd_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, stream, dout, (float*)dx, B, (int)L, (int)C);
+    else return vitmi_fail(VITMI_E_DTYPE, "token_mean: bad dtype");
+    return vitmi_check_launch("token_mean_bwd_kernel");
+  }
+  return 0;
+}

@@ -296,3 +296,48 @@ def scale_cast(x, out, scale=None, *, M, N, ldx=None, ldo=None):
     check(load().vitmi_scale_cast(x.data_ptr(), dtype_code(x), ldx or N, _ptr(scale), out.data_ptr(),
                                   dtype_code(out), ldo or N, M, N, _stream()), "vitmi_scale_cast")
     return out
+
+
+# ------------------------------------------------------------------ Swin ops ---
+def win_attn_fwd(qkv, out, lse, bias, mask, Bw, H, N, hd, Himg, Wimg, ws, shift, scale):
+    _need_cuda(qkv, out, lse, bias)
+    check(load().vitmi_win_attn_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), bias.data_ptr(), _ptr(mask),
+                                    dtype_code(qkv), Bw, H, N, hd, Himg, Wimg, ws, shift, float(scale), _stream()),
+          "vitmi_win_attn_fwd")
+
+
+def win_attn_bwd(qkv, dout, lse, bias, mask, dqkv, dbias, Bw, H, N, hd, Himg, Wimg, ws, shift, scale):
+    _need_cuda(qkv, dout, dqkv, dbias)
+    lib = load()
+    ws_buf = workspace(lib.vitmi_win_attn_bwd_workspace(Bw, H, N), qkv.device)
+    check(lib.vitmi_win_attn_bwd(qkv.data_ptr(), dout.data_ptr(), lse.data_ptr(), bias.data_ptr(), _ptr(mask),
+                                 dqkv.data_ptr(), dbias.data_ptr(), dtype_code(qkv), Bw, H, N, hd, Himg, Wimg, ws,
+                                 shift, float(scale), ws_buf.data_ptr(), ws_buf.numel(), _stream()),
+          "vitmi_win_attn_bwd")
+
+
+def relpos_bias_gather(table, index, bias, T, H, N):
+    check(load().vitmi_relpos_bias(table.data_ptr(), index.data_ptr(), bias.data_ptr(), None, None, T, H, N,
+                                   _stream()), "vitmi_relpos_bias(gather)")
+
+
+def relpos_bias_scatter(dbias, index, dtable, T, H, N):
+    check(load().vitmi_relpos_bias(None, index.data_ptr(), None, dbias.data_ptr(), dtable.data_ptr(), T, H, N,
+                                   _stream()), "vitmi_relpos_bias(scatter)")
+
+
+def patch_merge(src, dst, B, Hh, Ww, Cc, inverse=False):
+    _need_cuda(src, dst)
+    assert src.dtype == dst.dtype
+    check(load().vitmi_patch_merge(src.data_ptr(), dst.data_ptr(), dtype_code(src), B, Hh, Ww, Cc, int(inverse),
+                                   _stream()), "vitmi_patch_merge")
+
+
+def token_mean_fwd(x, out, B, L, Cc):
+    check(load().vitmi_token_mean(x.data_ptr(), out.data_ptr(), None, None, dtype_code(x), B, L, Cc, _stream()),
+          "vitmi_token_mean(fwd)")
+
+
+def token_mean_bwd(dout, dx, B, L, Cc):
+    check(load().vitmi_token_mean(None, None, dout.data_ptr(), dx.data_ptr(), dtype_code(dx), B, L, Cc, _stream()),
+          "vitmi_token_mean(bwd)")

@@ -25,6 +25,9 @@ class VisionModelZoo:
         # models/vision_all.py:44-49 / models/cait.py:13-18
         "cait": ["cait_M48", "cait_M36", "cait_S36", "cait_S24", "cait_S24_224", "cait_XS24", "cait_XXS24",
                  "cait_XXS24_224", "cait_XXS36", "cait_XXS36_224"],
+        # models/vision_all.py:50-69 (the 224 / window-7 classification variants)
+        "swin": ["swin_tiny_patch4_window7_224", "swin_small_patch4_window7_224", "swin_base_patch4_window7_224",
+                 "swin_large_patch4_window7_224"],
     }
     # name: (patch, embed_dim, depth, heads) — DINO vit_small / vit_base
     dino_cfg = {
@@ -95,6 +98,25 @@ class VisionModelZoo:
             model.head = cls.get_classifier_head(in_features=backbone_features, classifier_units=classifier,
                                                  classifier_act=classifier_act)
             model.head_dist = model.head
+        if return_separate:
+            _head = model.head
+            model.head = nn.Identity()
+            return model, _head
+        return model
+
+    @classmethod
+    def get_model_swin(cls, arch="swin_base_patch4_window7_224", pretrained=True, image_channels=3,
+                       classifier=None, classifier_act=GELU(), return_separate=False, **model_kwargs):
+        """models/vision_all.py:223-297.  The reference builds Swin with its config's DropPath rate,
+        which stays active in every forward; pass drop_path_rate=0 (the only rate the HIP path
+        supports so far) explicitly — it is not silently changed."""
+        from .swin import get_swin_model
+        assert image_channels == 3
+        model = get_swin_model(arch, pretrained=pretrained, **model_kwargs)
+        if isinstance(classifier, (int, list)):
+            backbone_features = model.norm.weight.data.shape[-1]
+            model.head = cls.get_classifier_head(in_features=backbone_features, classifier_units=classifier,
+                                                 classifier_act=classifier_act)
         if return_separate:
             _head = model.head
             model.head = nn.Identity()
