@@ -1,0 +1,44 @@
+"""LR lambdas of the harness (utils_network.py:35-73, 529-544) against hand-evaluated values."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_lr_lambdas():
+    from vit_torch_amd.network import LRSchedule
+    step = LRSchedule.get_step_fn(step=10, gamma=0.5)
+    assert [step(e) for e in (0, 9, 10, 19, 20, 30)] == [1.0, 1.0, 0.5, 0.5, 0.25, 0.125]
+    exp = LRSchedule.get_exp_fn(gamma=0.99)
+    assert exp(0) == 1.0 and abs(exp(10) - 0.99 ** 10) < 1e-15
+    cos = LRSchedule.get_cosine(step=20, min_scale=0.1)
+    assert abs(cos(0) - 1.0) < 1e-12
+    assert abs(cos(5) - (0.45 * (math.cos(0.25 * 2 * math.pi) + 1) + 0.1)) < 1e-12
+    assert abs(cos(10) - 1.0) < 1e-12          # mod(10/20, 0.5) = 0: the reference's saw-tooth restart
+    ce = LRSchedule.get_cosine_exp(step=20, min_scale=0.1, gamma=0.5)
+    assert abs(ce(5) - cos(5) * 0.5 ** 0.25) < 1e-12
+    assert LRSchedule.get_base_fn()(7) == 1.0
+
+
+def test_scheduler_table_and_none_quirk():
+    from vit_torch_amd.network import get_lr_scheduler
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=0.1, momentum=0.9)
+    sch = get_lr_scheduler(opt, "step", step=2, gamma=0.5)
+    lrs = []
+    for _ in range(5):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step(); sch.step()
+    assert np.allclose(lrs, [0.1, 0.1, 0.05, 0.05, 0.025])
+    opt2 = torch.optim.SGD([p], lr=0.1)
+    get_lr_scheduler(opt2, "none")
+    assert opt2.param_groups[0]["lr"] == 0.0            # 'none' -> lambda e: e
+    with pytest.raises(NotImplementedError):
+        get_lr_scheduler(opt2, "ca")
+
+
+def test_network_rejects_non_modules():
+    from vit_torch_amd.network import Network
+    with pytest.raises(ValueError):
+        Network(model="not a module")

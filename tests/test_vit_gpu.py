@@ -194,3 +194,31 @@ def test_vitb16_full_size_bf16_deviation_is_bounded(residual):
     assert worst < 8e-2, f"{worst_name}: {worst}"
     print(f"\nvitb16 bf16 (residual {residual}): logits rel err {e:.2e}, loss diff "
           f"{abs(loss.item()-loss_ref.item()):.2e}, worst grad-norm rel {worst:.2e} ({worst_name})")
+
+
+def test_network_fit_matches_reference_loop_fp32():
+    """Harness parity (utils_network.py:406-453 + LambdaLR per epoch :311-313): two epochs of
+    three batches with the step LR schedule against the same loop on the CPU oracle."""
+    from vit_torch_amd.network import LRSchedule, Network
+    cfg, K = TINY, 10
+    ref, m = make_pair(cfg, 10, "fp32")
+    batches = [data(4, 3, cfg["img_size"], K, seed=30 + i) for i in range(3)]
+    opt_ref = torch.optim.SGD(ref.parameters(), lr=0.05, momentum=0.9)
+    sch_ref = torch.optim.lr_scheduler.LambdaLR(opt_ref, LRSchedule.get_step_fn(step=1, gamma=0.5))
+    ref_losses, ref_correct = [], []
+    for _ in range(2):
+        for x, y in batches:
+            out = ref(x)
+            loss = F.cross_entropy(out, y)
+            opt_ref.zero_grad(); loss.backward(); opt_ref.step()
+            ref_losses.append(loss.item()); ref_correct.extend((out.argmax(-1) == y).tolist())
+        sch_ref.step()
+    net = Network(m, opt="sgd", lr=0.05, lr_type="step", lr_step=1, lr_gamma=0.5, device="cuda")
+    hist = net.fit(batches, epochs=2)
+    got_losses = hist[0]["train"]["loss"] + hist[1]["train"]["loss"]
+    got_correct = list(hist[0]["train"]["correct"]) + list(hist[1]["train"]["correct"])
+    assert max(abs(a - b) for a, b in zip(got_losses, ref_losses)) < 1e-4
+    assert got_correct == ref_correct
+    assert hist[1]["lr"] == pytest.approx(0.025)
+    for (n, pr), (_, pm) in zip(ref.named_parameters(), m.named_parameters()):
+        assert_close(f"param[{n}] after 2 epochs", pm.data, pr.data, 2e-4)
