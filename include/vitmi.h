@@ -96,6 +96,10 @@ typedef struct vitmi_gemm_desc {
    * tensor (models/cait.py:113).  batch <= 1 = plain GEMM. */
   int64_t batch, batch_inner;
   int64_t a_bs[2], b_bs[2], c_bs[2];
+  /* EPI_RESIDUAL only: per-row-group scale of the branch, C = R + rowscale[m/rows_per_group]
+   * * gamma[n]*(acc+bias) — DropPath's per-sample keep/keep_prob (timm DropPath as used at
+   * models/swin.py:203,267-268) with rows_per_group = tokens per image.  NULL -> 1. */
+  const float* rowscale; int64_t rows_per_group;
 } vitmi_gemm_desc;
 
 int vitmi_gemm(const vitmi_gemm_desc* d, void* stream);
@@ -125,13 +129,15 @@ size_t vitmi_layernorm_bwd_workspace(int64_t M, int64_t D);
  * over the M rows = the bias gradient of the Linear whose output feeds this residual
  * position (fused here to save a pass over g_out).  gb_scale (optional, fp32 [D]):
  * LayerScale of the branch that consumes gb_out — gb_out and gsum are then taken of
- * g_out * gb_scale (models/cait.py:148-149).  g_in may alias g_out. */
+ * g_out * gb_scale (models/cait.py:148-149); gb_rowscale (optional, fp32, one per
+ * rows_per_group rows): DropPath factor of that branch, applied the same way. */
 int vitmi_layernorm_bwd(const void* dy, int dy_dtype, int64_t dy_stride,
                         const void* x, int x_dtype, int64_t x_stride,
                         const float* mean, const float* rstd, const float* gamma,
                         const void* g_in, void* g_out, int g_dtype, int64_t g_stride,
                         void* gb_out, int gb_dtype, int64_t gb_stride,
                         float* dgamma, float* dbeta, float* gsum, const float* gb_scale,
+                        const float* gb_rowscale, int64_t rows_per_group,
                         int64_t M, int64_t D,
                         void* workspace, size_t workspace_bytes, void* stream);
 
@@ -221,9 +227,11 @@ int vitmi_token_mean(const void* x, float* out, const float* dout, void* dx, int
 int vitmi_cast(const void* src, int src_dtype, void* dst, int dst_dtype,
                int64_t n, void* stream);
 
-/* out[m*ldo+n] = cast(x[m*ldx+n] * scale[n]) (scale NULL -> 1): strided row copy with an
- * optional per-column LayerScale; also the plain strided copy/cast of row blocks */
+/* out[m*ldo+n] = cast(x[m*ldx+n] * scale[n] * rowscale[m/rows_per_group]) (NULL -> 1):
+ * strided row copy with optional per-column LayerScale / per-sample DropPath factor; also
+ * the plain strided copy/cast of row blocks */
 int vitmi_scale_cast(const void* x, int x_dtype, int64_t ldx, const float* scale,
+                     const float* rowscale, int64_t rows_per_group,
                      void* out, int out_dtype, int64_t ldo, int64_t M, int64_t N, void* stream);
 
 /* im2col for Conv2d(C, D, kernel=p, stride=p) (models/swin.py:434,445):

@@ -96,6 +96,13 @@ def test_gemm_epilogues(ops, dt):
         assert_close(f"residual[{rdt}]", X, r + gam * (acc + bias), TOL[rdt])
         ops.gemm(A, B, X, epilogue=EPI_RESIDUAL, R=dev(r, rdt), impl=GEMM_GENERIC)
         assert_close(f"residual-plain[{rdt}]", X, r + acc, TOL[rdt])
+        # DropPath: per-sample factor on the branch (6 samples x 25 rows), one sample dropped
+        rsc = torch.tensor([1.25, 0.0, 1.25, 1.25, 0.0, 1.25])
+        ops.gemm(A, B, X, epilogue=EPI_RESIDUAL, bias=bias_d, R=dev(r, rdt), rowscale=dev(rsc), rows_per_group=25,
+                 impl=GEMM_GENERIC)
+        want = r + rsc.repeat_interleave(25)[:, None] * (acc + bias)
+        assert_close(f"residual-droppath[{rdt}]", X, want, TOL[rdt])
+        assert torch.equal(X[25:50].float().cpu(), r[25:50]), "a dropped sample must pass the residual through"
     # dgelu
     aux = rd(gen((M, N), 9))
     Dg = torch.empty((M, N), device="cuda", dtype=dt)
@@ -172,6 +179,40 @@ def test_layernorm_bwd(ops, M, D, T, R):
         assert_close("ln.gb_out", Gb, gin + xr.grad, TOL[T])
     assert_close("ln.dgamma", dg, gr.grad, 1e-4)
     assert_close("ln.dbeta", db, br.grad, 1e-4)
+
+
+def test_layernorm_bwd_gb_row_and_column_scale(ops):
+    """Gb (and its column sum) carry LayerScale x DropPath of the consuming branch; g_out does not."""
+    M, D, rpg = 96, 128, 16
+    x, dy, gin = gen((M, D), 1), gen((M, D), 2), gen((M, D), 3)
+    g = 1 + 0.1 * gen((D,), 4)
+    col = gen((D,), 5)
+    row = torch.tensor([2.0, 0.0, 2.0, 2.0, 0.0, 0.0])
+    xr = x.clone().requires_grad_(True)
+    F.layer_norm(xr, (D,), g, torch.zeros(D), eps=1e-6).backward(dy)
+    mean, rstd = x.mean(-1), (x.var(-1, unbiased=False) + 1e-6).rsqrt()
+    G = torch.empty((M, D), device="cuda")
+    Gb = torch.empty((M, D), device="cuda", dtype=torch.bfloat16)
+    dg, db, gsum = (torch.empty(D, device="cuda") for _ in range(3))
+    ops.layernorm_bwd(dev(dy), dev(x), dev(mean), dev(rstd), dev(g), dev(gin), G, Gb, dg, db, gsum=gsum,
+                      gb_scale=dev(col), gb_rowscale=dev(row), rows_per_group=rpg)
+    want = gin + xr.grad
+    wb = want * col * row.repeat_interleave(rpg)[:, None]
+    assert_close("g_out", G, want, 2e-5)
+    assert_close("gb_out", Gb, wb, TOL[torch.bfloat16])
+    assert_close("gsum", gsum, wb.sum(0), 1e-4)
+
+
+def test_scale_cast_row_and_column(ops):
+    M, N, rpg = 60, 96, 12
+    x, col = gen((M, N), 1), gen((N,), 2)
+    row = torch.tensor([0.0, 1.5, 1.5, 0.0, 1.5])
+    out = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+    ops.scale_cast(dev(x), out, dev(col), M=M, N=N, rowscale=dev(row), rows_per_group=rpg)
+    assert_close("scale_cast", out, x * col * row.repeat_interleave(rpg)[:, None], TOL[torch.bfloat16])
+    o32 = torch.empty((M, N), device="cuda")
+    ops.scale_cast(dev(x), o32, None, M=M, N=N, rowscale=dev(row), rows_per_group=rpg)
+    assert torch.equal(o32.cpu(), x * row.repeat_interleave(rpg)[:, None])
 
 
 def test_layernorm_bwd_cls_rows_no_gin(ops):
@@ -390,6 +431,12 @@ def test_gemm_fast_epilogues(ops, pipe):
         assert_close(f"residual[{rdt}]", X, r + gam * (acc + bias), TOL[rdt] if rdt == bt else 1e-4)
         ops.gemm(A, B, X, epilogue=EPI_RESIDUAL, R=dev(r, rdt), impl=GEMM_FAST)
         assert_close(f"residual-plain[{rdt}]", X, r + acc, TOL[rdt] if rdt == bt else 1e-4)
+        rsc = torch.tensor([1.25, 0.0, 1.25, 1.25, 0.0, 1.25, 1.25, 1.25])      # 8 samples x 64 rows
+        ops.gemm(A, B, X, epilogue=EPI_RESIDUAL, bias=bias_d, R=dev(r, rdt), gamma=dev(gam), rowscale=dev(rsc),
+                 rows_per_group=64, impl=GEMM_FAST)
+        want = r + rsc.repeat_interleave(64)[:, None] * gam * (acc + bias)
+        assert_close(f"residual-droppath[{rdt}]", X, want, TOL[rdt] if rdt == bt else 1e-4)
+        assert torch.equal(X[64:128].float().cpu(), r[64:128])
     aux = bf16_round(gen((M, N), 9))
     Dg = torch.empty((M, N), device="cuda", dtype=bt)
     ops.gemm(A, Bt, Dg, b_kmajor=False, epilogue=EPI_DGELU, aux=dev(aux, bt), impl=GEMM_FAST)

@@ -160,6 +160,83 @@ def test_swin_tiny_bf16_close_to_oracle(residual):
     print(f"\nswin tiny bf16 (residual {residual}): logits rel err {e:.2e}, worst grad-norm rel err {worst:.2e}")
 
 
+def _keep_masks(cfg, B, rate, seed):
+    """Bernoulli(keep) draws per block and branch, nested [stage][block] -> (m_attn, m_mlp);
+    the very first block has rate 0 (linspace starts at 0) and ignores its masks."""
+    g = torch.Generator("cpu").manual_seed(seed)
+    dpr = torch.linspace(0, rate, sum(cfg["depths"])).tolist()
+    masks, i = [], 0
+    for d in cfg["depths"]:
+        st = []
+        for _ in range(d):
+            kp = 1.0 - dpr[i]
+            st.append(tuple(torch.bernoulli(torch.full((B,), kp), generator=g) for _ in range(2)))
+            i += 1
+        masks.append(st)
+    return masks
+
+
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+def test_swin_tiny_drop_path_matches_oracle_with_pinned_masks(compute):
+    """DropPath (models/swin.py:203,267-268) active as in the reference's training loop: the
+    same per-sample keep masks on both sides -> same logits and gradients."""
+    cfg = dict(TINY, drop_path_rate=0.5)
+    ref, m = make_pair(cfg, compute)
+    B = 6
+    masks = _keep_masks(cfg, B, 0.5, 3)
+    dropped = sum(int((k == 0).sum()) for st in masks for pair in st for k in pair)
+    assert dropped >= 4, "seed must drop a few branches or the test pins nothing"
+    from vit_torch_amd import CrossEntropyLoss
+    g = torch.Generator("cpu").manual_seed(0)
+    x, y = torch.randn(B, 3, 56, 56, generator=g), torch.randint(0, 10, (B,), generator=g)
+    lo = ref(x, keep_masks=masks)
+    lr = F.cross_entropy(lo, y)
+    ref.zero_grad(); lr.backward()
+    m.train()
+    m.drop_path_keep_masks = masks
+    out = m(x.cuda())
+    loss = CrossEntropyLoss()(out, y.cuda())
+    m.zero_grad(); loss.backward()
+    if compute == "fp32":
+        e = assert_close("logits", out, lo, 1e-4)
+        assert abs(loss.item() - lr.item()) < 1e-4
+        for (n, pr), (_, pm) in zip(ref.named_parameters(), m.named_parameters()):
+            assert_close(f"grad[{n}]", pm.grad, pr.grad, 3e-4)
+    else:
+        e = assert_close("logits", out, lo, 3e-2)
+        for (n, pr), (_, pm) in zip(ref.named_parameters(), m.named_parameters()):
+            gn_ref, gn = pr.grad.norm().item(), pm.grad.float().norm().item()
+            assert abs(gn - gn_ref) / max(gn_ref, 1e-12) < 8e-2, n
+    # eval mode: DropPath is the identity (nn.Module semantics)
+    m.eval()
+    with torch.no_grad():
+        assert_close("eval logits", m(x.cuda()), ref(x), 1e-4 if compute == "fp32" else 3e-2)
+    print(f"\nswin tiny drop-path {compute}: logits rel err {e:.2e}, {dropped} dropped branches")
+
+
+def test_swin_drop_path_random_draws_have_the_right_rate():
+    """Unpinned masks: a dropped sample's branch contributes nothing, so with rate r the
+    fraction of (sample, branch) pairs whose residual passes through unchanged is ~r."""
+    cfg = dict(TINY, depths=[2], num_heads=[2], drop_path_rate=0.6)
+    _, m = make_pair(cfg, "fp32")
+    m.train()
+    eng = m.engine()
+    B = 512
+    x = torch.randn(B, 3, 56, 56, device="cuda")
+    torch.manual_seed(5)
+    eng.forward(x, save=True)
+    blocks = eng.saved["stages"][0][0]
+    assert blocks[0][-1] is None and blocks[0][-2] is None      # block 0 has rate 0
+    rs1, rs2 = blocks[1][-2], blocks[1][-1]
+    for rs in (rs1, rs2):
+        vals = set(rs.unique().tolist())
+        assert vals <= {0.0, 2.5}, vals
+        frac = (rs == 0).float().mean().item()
+        assert 0.5 < frac < 0.7, frac
+    assert not torch.equal(rs1, rs2), "the two branches draw independent masks"
+    eng.saved = None
+
+
 def test_swin_t_full_size_fp32_logits_within_1e3():
     """BASELINE config 5 architecture (Swin-T, drop-path 0), batch 2, parity mode."""
     from oracle import swin_ref

@@ -35,6 +35,7 @@ class GemmDesc(C.Structure):
         ("workspace", c_vp), ("workspace_bytes", c_sz),
         ("batch", c_i64), ("batch_inner", c_i64),
         ("a_bs", c_i64 * 2), ("b_bs", c_i64 * 2), ("c_bs", c_i64 * 2),
+        ("rowscale", c_vp), ("rows_per_group", c_i64),
     ]
 
 
@@ -50,7 +51,7 @@ SIGNATURES = {
     "vitmi_layernorm_bwd_workspace": (c_sz, [c_i64, c_i64]),
     "vitmi_layernorm_bwd": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, C.c_int, c_i64, c_vp, c_vp, c_vp,
                                       c_vp, c_vp, C.c_int, c_i64, c_vp, C.c_int, c_i64, c_vp, c_vp, c_vp, c_vp,
-                                      c_i64, c_i64, c_vp, c_sz, c_vp]),
+                                      c_vp, c_i64, c_i64, c_i64, c_vp, c_sz, c_vp]),
     "vitmi_attn_fwd": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_i64, c_f32, c_vp]),
     "vitmi_attn_bwd_workspace": (c_sz, [c_i64, c_i64, c_i64]),
     "vitmi_attn_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_i64,
@@ -73,7 +74,7 @@ SIGNATURES = {
     "vitmi_patch_merge": (C.c_int, [c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_i64, C.c_int, c_vp]),
     "vitmi_token_mean": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_vp]),
     "vitmi_cast": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, c_i64, c_vp]),
-    "vitmi_scale_cast": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_vp]),
+    "vitmi_scale_cast": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, c_vp, c_i64, c_vp, C.c_int, c_i64, c_i64, c_i64, c_vp]),
     "vitmi_patchify": (C.c_int, [c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, C.c_int, c_i64, c_i64,
                                  c_i64, c_i64, c_i64, C.c_int, c_vp]),
     "vitmi_colsum_workspace": (c_sz, [c_i64, c_i64]),

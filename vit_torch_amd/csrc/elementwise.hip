@@ -30,12 +30,14 @@ __global__ void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, in
 // residual-stream gradient entering a LayerScale branch
 template <typename TS, typename TD>
 __global__ void scale_cast_kernel(const TS* __restrict__ x, int64_t ldx, const float* __restrict__ scale,
+                                  const float* __restrict__ rowscale, int64_t rpg,
                                   TD* __restrict__ out, int64_t ldo, int64_t M, int64_t N) {
   const int64_t n4 = N / 4, total = M * n4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t m = i / n4, n = (i % n4) * 4;
     f32x4 v = load4<TS>(x + m * ldx + n);
     if (scale) v *= *reinterpret_cast<const f32x4*>(scale + n);
+    if (rowscale) v *= rowscale[m / rpg];
     store4<TD>(out + m * ldo + n, v);
   }
 }
@@ -244,7 +246,8 @@ extern "C" int vitmi_cast(const void* src, int sd, void* dst, int dd, int64_t n,
   return vitmi_check_launch("cast_kernel");
 }
 
-extern "C" int vitmi_scale_cast(const void* x, int x_dtype, int64_t ldx, const float* scale, void* out,
+extern "C" int vitmi_scale_cast(const void* x, int x_dtype, int64_t ldx, const float* scale,
+                                const float* rowscale, int64_t rows_per_group, void* out,
                                 int out_dtype, int64_t ldo, int64_t M, int64_t N, void* stream_) {
   VITMI_REQUIRE(x && out && M > 0 && N > 0 && ldx >= N && ldo >= N, VITMI_E_BADARG, "scale_cast: bad argument");
   VITMI_REQUIRE(N % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && is_aligned(x, 4 * dtype_size(x_dtype)) &&
@@ -252,7 +255,7 @@ extern "C" int vitmi_scale_cast(const void* x, int x_dtype, int64_t ldx, const f
                 VITMI_E_ALIGN, "scale_cast: 4-element alignment required");
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   const unsigned grid = ew_grid(M * N / 4);
-#define SC(TS, TD) hipLaunchKernelGGL((scale_cast_kernel<TS, TD>), dim3(grid), dim3(EW_BLOCK), 0, stream, (const TS*)x, ldx, scale, (TD*)out, ldo, M, N)
+#define SC(TS, TD) hipLaunchKernelGGL((scale_cast_kernel<TS, TD>), dim3(grid), dim3(EW_BLOCK), 0, stream, (const TS*)x, ldx, scale, rowscale, rows_per_group > 0 ? rows_per_group : 1, (TD*)out, ldo, M, N)
   if (x_dtype == VITMI_F32 && out_dtype == VITMI_BF16) SC(float, bf16);
   else if (x_dtype == VITMI_F32 && out_dtype == VITMI_F32) SC(float, float);
   else if (x_dtype == VITMI_BF16 && out_dtype == VITMI_BF16) SC(bf16, bf16);

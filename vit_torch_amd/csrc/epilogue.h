@@ -14,6 +14,7 @@ struct EpiArgs {
   const float* pos; int64_t n_tok; int64_t ldpos; const float* cls;
   float alpha;
   int accumulate;
+  const float* rowscale; int64_t rpg;      // RESIDUAL: per-row-group branch scale (DropPath)
 };
 
 struct GemmArgs {
@@ -56,6 +57,7 @@ __device__ __forceinline__ float epi_value(const EpiArgs& e, int64_t m, int64_t 
     float v = acc + (e.bias ? e.bias[n] : 0.f);
     *v2 = v;                               // branch output before LayerScale (for d gamma)
     if (e.gamma) v *= e.gamma[n];
+    if (e.rowscale) v *= e.rowscale[m / e.rpg];
     return ld_any(e.R, m * e.ldr + n, e.r_bf16) + v;
   } else if constexpr (MODE == VITMI_EPI_DGELU) {
     return acc * dgelu_erf(ld_any(e.AUX, m * e.ldaux + n, e.aux_bf16));

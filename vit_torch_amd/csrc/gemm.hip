@@ -183,6 +183,8 @@ static int build_args(const vitmi_gemm_desc* d, GemmArgs* out) {
   e.pos = d->pos; e.n_tok = d->n_tok; e.ldpos = d->N; e.cls = d->cls;
   e.alpha = d->alpha == 0.f ? 1.f : d->alpha;
   e.accumulate = d->accumulate;
+  e.rowscale = d->epilogue == VITMI_EPI_RESIDUAL ? d->rowscale : nullptr;
+  e.rpg = d->rows_per_group > 0 ? d->rows_per_group : 1;
   VITMI_REQUIRE(g.batch == 1 || (d->epilogue == VITMI_EPI_STORE && !d->accumulate && g.batch % g.batch_inner == 0 && g.batch <= 65535),
                 VITMI_E_BADARG, "gemm: batched form supports EPI_STORE without accumulate, batch %% batch_inner == 0, batch <= 65535");
   switch (d->epilogue) {

@@ -77,6 +77,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
                                                      TGB* __restrict__ gb_out, int64_t gbs,
                                                      float* __restrict__ part, int want_gsum,
                                                      const float* __restrict__ gb_scale,
+                                                     const float* __restrict__ gb_rowscale, int64_t rpg,
                                                      int64_t M, int D) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [4][D]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
       }
     }
     const float c1 = wave_sum(s1) * invD, c2 = wave_sum(s2) * invD;
+    const float rsc = gb_rowscale ? gb_rowscale[row / rpg] : 1.f;
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
       const int c = (i * 64 + lane) * 4;
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
         // the GEMM-operand copy (and its column sum) carry the LayerScale of the branch
         // that will consume them: d(branch out) = g_out * gamma_branch
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] *= gsc[i][j];
+        for (int j = 0; j < 4; ++j) o[j] *= gsc[i][j] * rsc;
         if (gb_out) store4<TGB>(gb_out + row * gbs + c, o);
 #pragma unroll
         for (int j = 0; j < 4; ++j) gs[i][j] += o[j];
@@ -206,7 +208,8 @@ extern "C" int vitmi_layernorm_bwd(const void* dy, int dy_dtype, int64_t dy_stri
                                    const float* rstd, const float* gamma, const void* g_in,
                                    void* g_out, int g_dtype, int64_t g_stride, void* gb_out,
                                    int gb_dtype, int64_t gb_stride, float* dgamma, float* dbeta,
-                                   float* gsum, const float* gb_scale, int64_t M, int64_t D,
+                                   float* gsum, const float* gb_scale, const float* gb_rowscale,
+                                   int64_t rows_per_group, int64_t M, int64_t D,
                                    void* workspace, size_t workspace_bytes, void* stream_) {
   int rc = check_ln_common(x, x_dtype, x_stride, M, D, "layernorm_bwd");
   if (rc) return rc;
@@ -227,7 +230,8 @@ extern "C" int vitmi_layernorm_bwd(const void* dy, int dy_dtype, int64_t dy_stri
 #define LN_BWD(TDY, TX, TG, TGB)                                                               \
   hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TG, TGB>), dim3(nblk), dim3(256), lds, stream,    \
                      (const TDY*)dy, dy_stride, (const TX*)x, x_stride, mean, rstd, gamma,     \
-                     (const TG*)g_in, (TG*)g_out, g_stride, (TGB*)gb_out, gb_stride, part, gsum ? 1 : 0, gb_scale, M, (int)D)
+                     (const TG*)g_in, (TG*)g_out, g_stride, (TGB*)gb_out, gb_stride, part, gsum ? 1 : 0, gb_scale, gb_rowscale,       \
+                     rows_per_group > 0 ? rows_per_group : 1, M, (int)D)
   const int gbd = gb_out ? gb_dtype : dy_dtype;
   if (dy_dtype == VITMI_F32 && x_dtype == VITMI_F32 && g_dtype == VITMI_F32 && gbd == VITMI_F32) LN_BWD(float, float, float, float);
   else if (dy_dtype == VITMI_BF16 && x_dtype == VITMI_F32 && g_dtype == VITMI_F32 && gbd == VITMI_BF16) LN_BWD(bf16, float, float, bf16);

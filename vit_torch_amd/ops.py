@@ -51,7 +51,7 @@ def workspace(nbytes: int, device) -> torch.Tensor:
 
 def gemm(A, B, C_out, *, a_kmajor=True, b_kmajor=True, epilogue=EPI_STORE, bias=None, R=None,
          gamma=None, aux=None, C2=None, pos=None, n_tok=0, cls=None, alpha=1.0, accumulate=False,
-         impl=GEMM_AUTO):
+         impl=GEMM_AUTO, rowscale=None, rows_per_group=0):
     """C = epilogue(op(A) @ op(B)^T); see vitmi_gemm in include/vitmi.h."""
     _need_cuda(A, B, C_out)
     assert A.dim() == 2 and B.dim() == 2 and C_out.dim() == 2
@@ -93,6 +93,9 @@ def gemm(A, B, C_out, *, a_kmajor=True, b_kmajor=True, epilogue=EPI_STORE, bias=
     d.alpha = float(alpha)
     d.accumulate = int(accumulate)
     d.impl = impl
+    if rowscale is not None:
+        assert rowscale.dtype == torch.float32 and rows_per_group > 0 and rowscale.numel() * rows_per_group >= M
+        d.rowscale, d.rows_per_group = rowscale.data_ptr(), rows_per_group
     lib = load()
     need = lib.vitmi_gemm_workspace(C.byref(d))
     if need:
@@ -156,8 +159,8 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps, *, M=None, D=None, x_strid
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, g_in, g_out, gb_out, dgamma, dbeta, *, gsum=None,
-                  gb_scale=None, M=None, D=None, dy_stride=None, x_stride=None, g_stride=None,
-                  gb_stride=None):
+                  gb_scale=None, gb_rowscale=None, rows_per_group=0, M=None, D=None, dy_stride=None,
+                  x_stride=None, g_stride=None, gb_stride=None):
     _need_cuda(dy, x, g_out)
     D = D or x.shape[-1]
     M = M or dy.numel() // D
@@ -171,8 +174,8 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, g_in, g_out, gb_out, dgamma, dbeta, 
         _ptr(g_in), g_out.data_ptr(), dtype_code(g_out), g_stride if g_stride is not None else D,
         _ptr(gb_out), dtype_code(gb_out) if gb_out is not None else dtype_code(dy),
         gb_stride if gb_stride is not None else D,
-        dgamma.data_ptr(), dbeta.data_ptr(), _ptr(gsum), _ptr(gb_scale), M, D, ws.data_ptr(), ws.numel(),
-        _stream()),
+        dgamma.data_ptr(), dbeta.data_ptr(), _ptr(gsum), _ptr(gb_scale), _ptr(gb_rowscale), rows_per_group,
+        M, D, ws.data_ptr(), ws.numel(), _stream()),
         "vitmi_layernorm_bwd")
 
 
@@ -290,11 +293,12 @@ def colsum_mul(x, y, out, *, M=None, N=None, ldx=None, ldy=None):
     return out
 
 
-def scale_cast(x, out, scale=None, *, M, N, ldx=None, ldo=None):
-    """out[m, :N] = cast(x[m, :N] * scale); rows at strides ldx / ldo (elements)."""
+def scale_cast(x, out, scale=None, *, M, N, ldx=None, ldo=None, rowscale=None, rows_per_group=0):
+    """out[m, :N] = cast(x[m, :N] * scale * rowscale[m // rows_per_group]); rows at strides ldx / ldo."""
     _need_cuda(x, out)
-    check(load().vitmi_scale_cast(x.data_ptr(), dtype_code(x), ldx or N, _ptr(scale), out.data_ptr(),
-                                  dtype_code(out), ldo or N, M, N, _stream()), "vitmi_scale_cast")
+    check(load().vitmi_scale_cast(x.data_ptr(), dtype_code(x), ldx or N, _ptr(scale), _ptr(rowscale),
+                                  rows_per_group, out.data_ptr(), dtype_code(out), ldo or N, M, N, _stream()),
+          "vitmi_scale_cast")
     return out
 
 

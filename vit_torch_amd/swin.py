@@ -8,9 +8,15 @@ contract.  `forward` runs `SwinEngine`, an explicit forward/backward kernel sequ
 which tokens never leave token order: roll / window_partition / window_reverse are folded
 into the window-attention kernels' addressing.
 
-DropPath (models/swin.py:203,267-268): the reference leaves it active in every forward
-(it never calls .eval()); this first version of the row supports drop_path_rate = 0 only
-and refuses other rates instead of silently differing.
+DropPath (models/swin.py:203,267-268; per-block rates from linspace(0, drop_path_rate,
+sum(depths)), :520): in training mode each block draws two per-sample Bernoulli(keep)
+masks (attention branch, MLP branch); keep/keep_prob rides as the per-row-group scale of
+the branch GEMM's residual epilogue and of the matching backward `Gb` emission, so a
+dropped sample costs no extra pass.  The reference never calls .eval(), so its DropPath is
+active in every forward; this mirror follows nn.Module semantics (active iff
+`model.training`).  `model.drop_path_keep_masks` (nested [stage][block] -> (m_attn[B],
+m_mlp[B]) of 0/1) pins the draws for parity tests; None -> fresh draws from torch's
+device generator each forward.
 """
 from __future__ import annotations
 
@@ -62,9 +68,11 @@ class WindowAttention(nn.Module):
 
 
 class SwinTransformerBlock(nn.Module):
-    def __init__(self, dim, input_resolution, num_heads, window_size, shift_size, mlp_ratio, qkv_bias):
+    def __init__(self, dim, input_resolution, num_heads, window_size, shift_size, mlp_ratio, qkv_bias,
+                 drop_path=0.0):
         super().__init__()
         self.dim, self.input_resolution, self.num_heads = dim, input_resolution, num_heads
+        self.drop_path_rate = float(drop_path)
         self.window_size, self.shift_size = window_size, shift_size
         if min(input_resolution) <= window_size:      # models/swin.py:192-195
             self.shift_size = 0
@@ -87,12 +95,14 @@ class PatchMerging(nn.Module):
 
 
 class BasicLayer(nn.Module):
-    def __init__(self, dim, input_resolution, depth, num_heads, window_size, mlp_ratio, qkv_bias, downsample):
+    def __init__(self, dim, input_resolution, depth, num_heads, window_size, mlp_ratio, qkv_bias, downsample,
+                 drop_path=0.0):
         super().__init__()
         self.dim, self.input_resolution, self.depth = dim, input_resolution, depth
         self.blocks = nn.ModuleList([
             SwinTransformerBlock(dim, input_resolution, num_heads, window_size,
-                                 0 if i % 2 == 0 else window_size // 2, mlp_ratio, qkv_bias)
+                                 0 if i % 2 == 0 else window_size // 2, mlp_ratio, qkv_bias,
+                                 drop_path[i] if isinstance(drop_path, (list, tuple)) else drop_path)
             for i in range(depth)])
         self.downsample = PatchMerging(input_resolution, dim) if downsample else None
 
@@ -119,9 +129,8 @@ class SwinTransformer(nn.Module):
         if drop_rate or attn_drop_rate or qk_scale is not None or ape or use_checkpoint:
             raise VitmiError("dropout / qk_scale / ape / checkpointing are not supported (the reference's configs "
                              "never set them, models/swin.py:768-820)")
-        if drop_path_rate:
-            raise VitmiError("drop_path_rate != 0 is not supported yet by the HIP Swin path; construct with "
-                             "drop_path_rate=0 (see module docstring)")
+        if not 0.0 <= drop_path_rate < 1.0:
+            raise VitmiError("drop_path_rate must be in [0, 1)")
         if norm_layer is not nn.LayerNorm:
             raise VitmiError("norm_layer must be nn.LayerNorm (eps 1e-5), as everywhere in models/swin.py")
         self.num_classes = num_classes
@@ -135,9 +144,12 @@ class SwinTransformer(nn.Module):
         self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim, patch_norm)
         pr = self.patch_embed.patches_resolution
         self.patches_resolution = pr
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(depths))]   # models/swin.py:520
+        self.drop_path_keep_masks = None
         self.layers = nn.ModuleList([
             BasicLayer(int(embed_dim * 2 ** i), (pr[0] // 2 ** i, pr[1] // 2 ** i), depths[i], num_heads[i],
-                       window_size, mlp_ratio, qkv_bias, downsample=i < self.num_layers - 1)
+                       window_size, mlp_ratio, qkv_bias, downsample=i < self.num_layers - 1,
+                       drop_path=dpr[sum(depths[:i]):sum(depths[:i + 1])])
             for i in range(self.num_layers)])
         self.norm = nn.LayerNorm(self.num_features)
         self.avgpool = nn.AdaptiveAvgPool1d(1)
@@ -265,13 +277,24 @@ class SwinEngine:
         else:
             X = Y
         stages = []
-        for layer in m.layers:
+        for si, layer in enumerate(m.layers):
             Hh, Ww = layer.input_resolution
             C = layer.dim
             M = B * Hh * Ww
+            L = Hh * Ww
             blocks = []
-            for blk in layer.blocks:
+            for bi, blk in enumerate(layer.blocks):
                 a, mlp = blk.attn, blk.mlp
+                rs1 = rs2 = None
+                if m.training and blk.drop_path_rate > 0.0:
+                    # timm DropPath: per-sample Bernoulli(keep) / keep on each of the two branches
+                    keep = 1.0 - blk.drop_path_rate
+                    if m.drop_path_keep_masks is not None:
+                        k1, k2 = m.drop_path_keep_masks[si][bi]
+                        rs = torch.stack([k1, k2]).to(device=dev, dtype=f32) / keep
+                    else:
+                        rs = torch.empty((2, B), dtype=f32, device=dev).bernoulli_(keep).div_(keep)
+                    rs1, rs2 = rs[0].contiguous(), rs[1].contiguous()
                 ws, sh, H = blk.window_size, blk.shift_size, a.num_heads
                 hd = C // H
                 N = ws * ws
@@ -287,7 +310,8 @@ class SwinEngine:
                 O, lse = new(M, C, T), vec(Bw * H * N)
                 ops.win_attn_fwd(qkv, O, lse, bias, blk.attn_mask, Bw, H, N, hd, Hh, Ww, ws, sh, a.scale)
                 X1 = new(M, C, R)
-                self._gemm(O, self._w(a.proj.weight), X1, epilogue=EPI_RESIDUAL, bias=pk.f32(a.proj.bias), R=X)
+                self._gemm(O, self._w(a.proj.weight), X1, epilogue=EPI_RESIDUAL, bias=pk.f32(a.proj.bias), R=X,
+                           rowscale=rs1, rows_per_group=L)
                 ln2, mean2, rstd2 = new(M, C, T), vec(M), vec(M)
                 ops.layernorm_fwd(X1, pk.f32(blk.norm2.weight), pk.f32(blk.norm2.bias), ln2, mean2, rstd2,
                                   blk.norm2.eps, M=M, D=C)
@@ -295,9 +319,10 @@ class SwinEngine:
                 pre, hid = new(M, Dh, T), new(M, Dh, T)
                 self._gemm(ln2, self._w(mlp.fc1.weight), hid, epilogue=EPI_BIAS_GELU, bias=pk.f32(mlp.fc1.bias), C2=pre)
                 X2 = new(M, C, R)
-                self._gemm(hid, self._w(mlp.fc2.weight), X2, epilogue=EPI_RESIDUAL, bias=pk.f32(mlp.fc2.bias), R=X1)
+                self._gemm(hid, self._w(mlp.fc2.weight), X2, epilogue=EPI_RESIDUAL, bias=pk.f32(mlp.fc2.bias), R=X1,
+                           rowscale=rs2, rows_per_group=L)
                 if save:
-                    blocks.append((X, ln1, mean1, rstd1, qkv, bias, O, lse, X1, ln2, mean2, rstd2, pre, hid))
+                    blocks.append((X, ln1, mean1, rstd1, qkv, bias, O, lse, X1, ln2, mean2, rstd2, pre, hid, rs1, rs2))
                 X = X2
             merge = None
             if layer.downsample is not None:
@@ -316,8 +341,7 @@ class SwinEngine:
             if save:
                 stages.append((blocks, merge))
         # final norm -> token mean -> head
-        Hh, Ww = m.layers[-1].input_resolution
-        L, C = Hh * Ww, m.num_features
+        C = m.num_features
         M = B * L
         xn, meanf, rstdf = new(M, C, f32), vec(M), vec(M)
         ops.layernorm_fwd(X, pk.f32(m.norm.weight), pk.f32(m.norm.bias), xn, meanf, rstdf, m.norm.eps, M=M, D=C)
@@ -378,8 +402,10 @@ class SwinEngine:
         ops.token_mean_bwd(d, dxn, B, L, C)
         G, Gb = new(M, C, R), new(M, C, T)
         last_blk = m.layers[-1].blocks[-1]
+        # Gb = (dropped-path-scaled) gradient of the last block's MLP branch output
         ops.layernorm_bwd(dxn, s["Xf"], s["meanf"], s["rstdf"], pk.f32(m.norm.weight), None, G, Gb,
-                          pk.g(m.norm.weight), pk.g(m.norm.bias), gsum=pk.g(last_blk.mlp.fc2.bias), M=M, D=C)
+                          pk.g(m.norm.weight), pk.g(m.norm.bias), gsum=pk.g(last_blk.mlp.fc2.bias),
+                          gb_rowscale=s["stages"][-1][0][-1][-1], rows_per_group=L, M=M, D=C)
         self._ready(m.norm, *([m.head] if self.head else []))
 
         layers = list(m.layers)
@@ -389,6 +415,7 @@ class SwinEngine:
             Hh, Ww = layer.input_resolution
             C = layer.dim
             M = B * Hh * Ww
+            L = Hh * Ww
             if layer.downsample is not None:
                 # G / Gb currently belong to the NEXT stage's input [M/4, 2C]
                 ds = layer.downsample
@@ -402,14 +429,15 @@ class SwinEngine:
                                   pk.g(ds.norm.weight), pk.g(ds.norm.bias), M=M2, D=4 * C)
                 G, Gb = new(M, C, R), new(M, C, T)
                 ops.patch_merge(Gm, G, B, Hh, Ww, C, inverse=True)
-                ops.scale_cast(G, Gb, None, M=M, N=C)
+                ops.scale_cast(G, Gb, None, M=M, N=C, rowscale=blocks_saved[-1][-1], rows_per_group=L)
                 ops.colsum(Gb, pk.g(layer.blocks[-1].mlp.fc2.bias))
                 self._ready(ds)
             blist = list(layer.blocks)
             for bi in range(len(blist) - 1, -1, -1):
                 blk = blist[bi]
                 a, mlp = blk.attn, blk.mlp
-                X, ln1, mean1, rstd1, qkv, bias, O, lse, X1, ln2, mean2, rstd2, pre, hid = blocks_saved.pop()
+                X, ln1, mean1, rstd1, qkv, bias, O, lse, X1, ln2, mean2, rstd2, pre, hid, rs1, _ = blocks_saved.pop()
+                rs_prev = blocks_saved[-1][-1] if bi > 0 else None     # MLP-branch factor of the block before
                 ws, sh, H = blk.window_size, blk.shift_size, a.num_heads
                 hd, N = C // H, ws * ws
                 Bw = B * (Hh // ws) * (Ww // ws)
@@ -422,7 +450,8 @@ class SwinEngine:
                 self._gemm(dH, ln2, pk.g(mlp.fc1.weight), a_kmajor=False, b_kmajor=False)
                 ops.colsum(dH, pk.g(mlp.fc1.bias))
                 ops.layernorm_bwd(dln2, X1, mean2, rstd2, pk.f32(blk.norm2.weight), G, G, Gb,
-                                  pk.g(blk.norm2.weight), pk.g(blk.norm2.bias), gsum=pk.g(a.proj.bias), M=M, D=C)
+                                  pk.g(blk.norm2.weight), pk.g(blk.norm2.bias), gsum=pk.g(a.proj.bias),
+                                  gb_rowscale=rs1, rows_per_group=L, M=M, D=C)
                 dO = new(M, C, T)
                 self._gemm(Gb, self._w(a.proj.weight), dO, b_kmajor=False)
                 self._gemm(Gb, O, pk.g(a.proj.weight), a_kmajor=False, b_kmajor=False)
@@ -439,7 +468,8 @@ class SwinEngine:
                 prev_bias = blist[bi - 1].mlp.fc2.bias if bi > 0 else None
                 ops.layernorm_bwd(dln1, X, mean1, rstd1, pk.f32(blk.norm1.weight), G, G, Gb,
                                   pk.g(blk.norm1.weight), pk.g(blk.norm1.bias),
-                                  gsum=pk.g(prev_bias) if prev_bias is not None else None, M=M, D=C)
+                                  gsum=pk.g(prev_bias) if prev_bias is not None else None,
+                                  gb_rowscale=rs_prev, rows_per_group=L, M=M, D=C)
                 self._ready(blk)
 
         # patch embedding (+ its LayerNorm)

@@ -107,9 +107,8 @@ class VisionModelZoo:
     @classmethod
     def get_model_swin(cls, arch="swin_base_patch4_window7_224", pretrained=True, image_channels=3,
                        classifier=None, classifier_act=GELU(), return_separate=False, **model_kwargs):
-        """models/vision_all.py:223-297.  The reference builds Swin with its config's DropPath rate,
-        which stays active in every forward; pass drop_path_rate=0 (the only rate the HIP path
-        supports so far) explicitly — it is not silently changed."""
+        """models/vision_all.py:223-297.  The model is built with its config's DropPath rate
+        (models/swin.py:768-820), active while `model.training` (see swin.py's docstring)."""
         from .swin import get_swin_model
         assert image_channels == 3
         model = get_swin_model(arch, pretrained=pretrained, **model_kwargs)
