@@ -100,6 +100,13 @@ typedef struct vitmi_gemm_desc {
    * * gamma[n]*(acc+bias) — DropPath's per-sample keep/keep_prob (timm DropPath as used at
    * models/swin.py:203,267-268) with rows_per_group = tokens per image.  NULL -> 1. */
   const float* rowscale; int64_t rows_per_group;
+  /* EPI_DGELU on the aligned (256x256-tile) path only: optional fp32 [M/128][N] (ld = N);
+   * row r receives the column sums of the fp32 epilogue results of rows [128r, 128r+128).
+   * Their sum over r (vitmi_colsum) is the bias gradient of the Linear whose
+   * pre-activation is AUX (torch.nn.Linear backward, db = sum_rows dH) — fused here so dH
+   * is not read back from HBM just to be summed.  Ask vitmi_gemm_uses_fast() first: any
+   * other path rejects a non-NULL colsum_part. */
+  float* colsum_part;
 } vitmi_gemm_desc;
 
 int vitmi_gemm(const vitmi_gemm_desc* d, void* stream);
@@ -153,10 +160,14 @@ int vitmi_attn_fwd(const void* qkv, void* out, float* lse, int dtype,
                    int64_t B, int64_t N, int64_t H, int64_t hd, float scale,
                    void* stream);
 size_t vitmi_attn_bwd_workspace(int64_t B, int64_t N, int64_t H);
+/* dbias_part (optional, bf16 kernels only): fp32 [vitmi_attn_bwd_dbias_rows(B, N)][3*H*hd];
+ * each row holds the column sums of the dqkv rows one workgroup produced, so their sum
+ * (vitmi_colsum) is the qkv Linear's bias gradient without reading dqkv back. */
+int64_t vitmi_attn_bwd_dbias_rows(int64_t B, int64_t N);
 int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout,
                    const float* lse, void* dqkv, int dtype,
                    int64_t B, int64_t N, int64_t H, int64_t hd, float scale,
-                   void* workspace, size_t workspace_bytes, void* stream);
+                   float* dbias_part, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------- CaiT ops --
  * Talking-heads softmax (models/cait.py:118-122) on score tensors [B,H,N,ld] (row length

@@ -274,6 +274,19 @@ def test_attention_fwd_bwd(ops, dt, B, N, H, hd):
     d = dqkv.float().cpu().view(B, N, 3, H, hd)
     for i, nm in enumerate("qkv"):
         assert_close(f"attn.d{nm}", d[:, :, i], g[:, :, i], tol if dt == torch.float32 else 2.5e-2)
+    if dt == torch.bfloat16:
+        # fused qkv-bias gradient: per-workgroup column sums of dqkv, same dqkv bits as without
+        rows = ops.attn_bwd_dbias_rows(B, N)
+        part = torch.full((rows, 3 * H * hd), float("nan"), device="cuda")
+        dqkv2 = torch.empty_like(dqkv)
+        ops.attn_bwd(QKV, O, dev(do, dt), lse, dqkv2, B, N, H, hd, scale, dbias_part=part)
+        assert torch.equal(dqkv2, dqkv)
+        assert rows % B == 0
+        per_img = part.view(B, rows // B, -1).sum(1)
+        want = dqkv.float().view(B, N, -1).sum(1)
+        # the kernel sums the fp32 values before they are rounded to bf16 for dqkv
+        assert_close("attn.dbias_part", per_img, want, 1.5e-2)
+        assert_close("attn.dbias", part.sum(0), qr.grad.view(B * N, -1).sum(0), 2.5e-2)
 
 
 def test_attention_online_softmax_rescale_branch(ops):
@@ -441,6 +454,21 @@ def test_gemm_fast_epilogues(ops, pipe):
     Dg = torch.empty((M, N), device="cuda", dtype=bt)
     ops.gemm(A, Bt, Dg, b_kmajor=False, epilogue=EPI_DGELU, aux=dev(aux, bt), impl=GEMM_FAST)
     assert_close("dgelu", Dg, acc * gelu_grad(aux), tol)
+    # fused bias gradient: column sums per 128-row group (256x256-tile path only)
+    from vit_torch_amd import _lib
+    if ops.gemm_uses_fast(M, N, K, b_kmajor=False, epilogue=EPI_DGELU, colsum_part=True):
+        part = torch.full((M // 128, N), float("nan"), device="cuda")
+        Dg2 = torch.empty_like(Dg)
+        ops.gemm(A, Bt, Dg2, b_kmajor=False, epilogue=EPI_DGELU, aux=dev(aux, bt), impl=GEMM_FAST, colsum_part=part)
+        assert torch.equal(Dg2, Dg)
+        assert_close("dgelu.colsum_part", part, (acc * gelu_grad(aux)).view(M // 128, 128, N).sum(1), 2e-3)
+        out = torch.empty(N, device="cuda")
+        ops.colsum(part, out)
+        assert_close("dgelu.colsum", out, (acc * gelu_grad(aux)).sum(0), 2e-3)
+    else:
+        with pytest.raises(_lib.VitmiError):
+            ops.gemm(A, Bt, Dg, b_kmajor=False, epilogue=EPI_DGELU, aux=dev(aux, bt), impl=GEMM_FAST,
+                     colsum_part=torch.empty((M // 128, N), device="cuda"))
     n_tok = 64
     pos, cls = gen((n_tok, N), 10), gen((N,), 11)
     t = torch.arange(M) % n_tok

@@ -36,6 +36,7 @@ class GemmDesc(C.Structure):
         ("batch", c_i64), ("batch_inner", c_i64),
         ("a_bs", c_i64 * 2), ("b_bs", c_i64 * 2), ("c_bs", c_i64 * 2),
         ("rowscale", c_vp), ("rows_per_group", c_i64),
+        ("colsum_part", c_vp),
     ]
 
 
@@ -54,8 +55,9 @@ SIGNATURES = {
                                       c_vp, c_i64, c_i64, c_i64, c_vp, c_sz, c_vp]),
     "vitmi_attn_fwd": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_i64, c_f32, c_vp]),
     "vitmi_attn_bwd_workspace": (c_sz, [c_i64, c_i64, c_i64]),
+    "vitmi_attn_bwd_dbias_rows": (c_i64, [c_i64, c_i64]),
     "vitmi_attn_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_i64,
-                                 c_f32, c_vp, c_sz, c_vp]),
+                                 c_f32, c_vp, c_vp, c_sz, c_vp]),
     "vitmi_th_softmax_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp]),
     "vitmi_th_softmax_bwd_workspace": (c_sz, [c_i64, c_i64, c_i64]),
     "vitmi_th_softmax_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int,

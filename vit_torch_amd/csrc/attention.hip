@@ -118,6 +118,45 @@ __device__ __forceinline__ void store_T_tile(bf16* dst_row, const f32x16 (&acc)[
     }
 }
 
+// Column sums of a transposed accumulator over the wave's 32 rows (the lanes lr of each
+// half), for the fused qkv-bias gradient.  One 32-row x 32-lane block (16 values per lane)
+// at a time, to keep the register cost at 16: a transposing butterfly — at step s lane
+// pairs (lr, lr ^ 2^s) split the remaining values between them and add — leaves ONE
+// total per lane after 4 steps (15 shuffles instead of 4 per value); the fifth lane bit
+// is folded by a plain add.  dst[d] (LDS, HD floats, this wave's) receives the sum of
+// element d; rows with valid == false count 0.
+__device__ __forceinline__ void colsum_T_block(float* dst32, const f32x16& acc, float mul, bool valid,
+                                               int lr, int h5) {
+  float v[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = valid ? acc[r] * mul : 0.f;
+  int e = 0;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int cnt = 8 >> s;
+    const bool up = (lr >> s) & 1;
+#pragma unroll
+    for (int i = 0; i < cnt; ++i) {
+      float lo = v[i], hi = v[i + cnt];
+      // opaque copies: otherwise the two selects are folded into v[up ? i + cnt : i], a
+      // dynamically indexed register array (a 16-way compare/select chain per access)
+      asm volatile("" : "+v"(lo), "+v"(hi));
+      const float keep = up ? hi : lo;
+      const float send = up ? lo : hi;
+      v[i] = keep + __shfl_xor(send, 1 << s, 64);
+    }
+    e += up ? cnt : 0;
+  }
+  v[0] += __shfl_xor(v[0], 16, 64);
+  if (lr < 16) dst32[8 * (e >> 2) + 4 * h5 + (e & 3)] = v[0];
+}
+template <int HD>
+__device__ __forceinline__ void colsum_T_tile(float* dst, const f32x16 (&acc)[HD / 32], float mul, bool valid,
+                                              int lr, int h5) {
+#pragma unroll
+  for (int db = 0; db < HD / 32; ++db) colsum_T_block(dst + db * 32, acc[db], mul, valid, lr, h5);
+}
+
 // rows owned per workgroup / rows streamed per chunk for a block of nw waves
 __device__ __forceinline__ int chunk_rows(int nw) { return 32 * (nw < 4 ? nw : 4); }
 
@@ -254,13 +293,14 @@ __global__ void attn_delta_kernel(const bf16* __restrict__ out, const bf16* __re
 }
 
 // ------------------------------------------------- backward: dK and dV ---
-template <int HD>
+template <int HD, bool DBIAS>
 __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(const bf16* __restrict__ qkv,
                                                             const bf16* __restrict__ dout,
                                                             const float* __restrict__ lse,
                                                             const float* __restrict__ delta,
                                                             bf16* __restrict__ dqkv, int N, int H,
-                                                            float scale, float scale_log2e) {
+                                                            float scale, float scale_log2e,
+                                                            float* __restrict__ dbias_part) {
   using C = AttnCfg<HD>;
   constexpr int QS = C::KS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -363,16 +403,32 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(const bf16* __restri
     store_T_tile<HD>(row + H * HD, dk, scale, h5);
     store_T_tile<HD>(row + 2 * H * HD, dv, 1.f, h5);
   }
+  if constexpr (DBIAS) {
+    // per-(image, row block) column sums of dK and dV: the k and v thirds of the qkv bias
+    // gradient, so that dqkv is not read back just to be summed
+    float* red = reinterpret_cast<float*>(smem);
+    __syncthreads();           // every wave is done with the staged Q / dO
+    colsum_T_tile<HD>(red + (w * 2 + 0) * HD, dk, scale, active && key < N, lr, h5);
+    colsum_T_tile<HD>(red + (w * 2 + 1) * HD, dv, 1.f, active && key < N, lr, h5);
+    __syncthreads();
+    for (int i = tid; i < 2 * HD; i += nthr) {
+      const int which = i / HD, d = i % HD;
+      float t = 0.f;
+      for (int ww = 0; ww < nw; ++ww) t += red[(ww * 2 + which) * HD + d];
+      dbias_part[((int64_t)b * gridDim.x + blockIdx.x) * ts + (1 + which) * H * HD + h * HD + d] = t;
+    }
+  }
 }
 
 // --------------------------------------------------------- backward: dQ ---
-template <int HD>
+template <int HD, bool DBIAS>
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv,
                                                           const bf16* __restrict__ dout,
                                                           const float* __restrict__ lse,
                                                           const float* __restrict__ delta,
                                                           bf16* __restrict__ dqkv, int N, int H,
-                                                          float scale, float scale_log2e) {
+                                                          float scale, float scale_log2e,
+                                                          float* __restrict__ dbias_part) {
   using C = AttnCfg<HD>;
   constexpr int KS = C::KS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -456,6 +512,17 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
   }
   const int q = q0 + lr;
   if (q < N) store_T_tile<HD>(dqkv + (int64_t)(b * (int64_t)N + q) * ts + h * HD, dq, scale, h5);
+  if constexpr (DBIAS) {
+    float* red = reinterpret_cast<float*>(smem);
+    __syncthreads();
+    colsum_T_tile<HD>(red + w * HD, dq, scale, active && q < N, lr, h5);
+    __syncthreads();
+    for (int i = tid; i < HD; i += nthr) {
+      float t = 0.f;
+      for (int ww = 0; ww < nw; ++ww) t += red[ww * HD + i];
+      dbias_part[((int64_t)b * gridDim.x + blockIdx.x) * ts + h * HD + i] = t;
+    }
+  }
 }
 
 inline int attn_waves(int64_t N) {
@@ -501,11 +568,18 @@ extern "C" size_t vitmi_attn_bwd_workspace(int64_t B, int64_t N, int64_t H) {
   return (size_t)(B * N * H) * sizeof(float);
 }
 
+extern "C" int64_t vitmi_attn_bwd_dbias_rows(int64_t B, int64_t N) {
+  const int nw = attn_waves(N);
+  return B * ((N + 32 * nw - 1) / (32 * nw));
+}
+
 extern "C" int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
                               void* dqkv, int dtype, int64_t B, int64_t N, int64_t H, int64_t hd,
-                              float scale, void* workspace, size_t workspace_bytes, void* stream_) {
+                              float scale, float* dbias_part, void* workspace, size_t workspace_bytes,
+                              void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   VITMI_REQUIRE(out && dout && lse && dqkv, VITMI_E_BADARG, "attn_bwd: null argument");
+  VITMI_REQUIRE(!dbias_part || dtype == VITMI_BF16, VITMI_E_DTYPE, "attn_bwd: dbias_part is produced by the bf16 kernels only");
   VITMI_REQUIRE(workspace && workspace_bytes >= vitmi_attn_bwd_workspace(B, N, H), VITMI_E_WORKSPACE, "attn_bwd: workspace too small");
   float* delta = reinterpret_cast<float*>(workspace);
   if (dtype == VITMI_F32)
@@ -516,7 +590,7 @@ extern "C" int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout
   const int64_t rows = B * N * H;
   const int nw = attn_waves(N);
   dim3 grid((unsigned)((N + 32 * nw - 1) / (32 * nw)), (unsigned)(B * H));
-#define LAUNCH_BWD(HDV)                                                                                  \
+#define LAUNCH_BWD(HDV, DB)                                                                              \
   do {                                                                                                   \
     const int64_t threads = rows * (HDV / 8);                                                            \
     hipLaunchKernelGGL((attn_delta_kernel<HDV>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,  \
@@ -524,16 +598,19 @@ extern "C" int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout
     rc = vitmi_check_launch("attn_delta_kernel");                                                        \
     if (rc) return rc;                                                                                   \
     const size_t lds_a = 2 * CHUNK_MAX * AttnCfg<HDV>::KS + 2 * CHUNK_MAX * sizeof(float);               \
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HDV>), grid, dim3(64 * nw), lds_a, stream, (const bf16*)qkv, \
-                       (const bf16*)dout, lse, delta, (bf16*)dqkv, (int)N, (int)H, scale, scale * LOG2E); \
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HDV, DB>), grid, dim3(64 * nw), lds_a, stream,              \
+                       (const bf16*)qkv, (const bf16*)dout, lse, delta, (bf16*)dqkv, (int)N, (int)H,     \
+                       scale, scale * LOG2E, dbias_part);                                                \
     rc = vitmi_check_launch("attn_bwd_dkdv_kernel");                                                     \
     if (rc) return rc;                                                                                   \
     const size_t lds_b = 2 * CHUNK_MAX * AttnCfg<HDV>::KS;                                               \
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<HDV>), grid, dim3(64 * nw), lds_b, stream, (const bf16*)qkv,  \
-                       (const bf16*)dout, lse, delta, (bf16*)dqkv, (int)N, (int)H, scale, scale * LOG2E); \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<HDV, DB>), grid, dim3(64 * nw), lds_b, stream,                \
+                       (const bf16*)qkv, (const bf16*)dout, lse, delta, (bf16*)dqkv, (int)N, (int)H,     \
+                       scale, scale * LOG2E, dbias_part);                                                \
     rc = vitmi_check_launch("attn_bwd_dq_kernel");                                                       \
   } while (0)
-  if (hd == 64) LAUNCH_BWD(64); else LAUNCH_BWD(32);
+  if (hd == 64) { if (dbias_part) LAUNCH_BWD(64, true); else LAUNCH_BWD(64, false); }
+  else          { if (dbias_part) LAUNCH_BWD(32, true); else LAUNCH_BWD(32, false); }
 #undef LAUNCH_BWD
   return rc;
 }

@@ -15,6 +15,7 @@ struct EpiArgs {
   float alpha;
   int accumulate;
   const float* rowscale; int64_t rpg;      // RESIDUAL: per-row-group branch scale (DropPath)
+  float* colsum_part;                      // DGELU, fast path: [M/128][N] column sums of C
 };
 
 struct GemmArgs {

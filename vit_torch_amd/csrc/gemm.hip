@@ -185,6 +185,8 @@ static int build_args(const vitmi_gemm_desc* d, GemmArgs* out) {
   e.accumulate = d->accumulate;
   e.rowscale = d->epilogue == VITMI_EPI_RESIDUAL ? d->rowscale : nullptr;
   e.rpg = d->rows_per_group > 0 ? d->rows_per_group : 1;
+  e.colsum_part = d->colsum_part;
+  VITMI_REQUIRE(!e.rowscale || (d->M < (1ll << 32) && e.rpg < (1ll << 32)), VITMI_E_SHAPE, "gemm: rowscale needs M < 2^32");
   VITMI_REQUIRE(g.batch == 1 || (d->epilogue == VITMI_EPI_STORE && !d->accumulate && g.batch % g.batch_inner == 0 && g.batch <= 65535),
                 VITMI_E_BADARG, "gemm: batched form supports EPI_STORE without accumulate, batch %% batch_inner == 0, batch <= 65535");
   switch (d->epilogue) {
@@ -235,6 +237,8 @@ extern "C" int vitmi_gemm(const vitmi_gemm_desc* d, void* stream_) {
     VITMI_REQUIRE(fast_ok, VITMI_E_SHAPE, "gemm: VITMI_GEMM_FAST requested but shape/dtype/alignment unsupported (M=%lld N=%lld K=%lld)",
                   (long long)d->M, (long long)d->N, (long long)d->K);
   if (fast_ok && d->impl != VITMI_GEMM_GENERIC) return gemm_fast_launch(g, stream);
+  VITMI_REQUIRE(!d->colsum_part, VITMI_E_BADARG,
+                "gemm: colsum_part is produced only by the aligned bf16 path with EPI_DGELU (ask vitmi_gemm_uses_fast)");
 
   dim3 grid((unsigned)((g.N + GBN - 1) / GBN), (unsigned)((g.M + GBM - 1) / GBM), (unsigned)g.batch);
   VITMI_REQUIRE(grid.y <= 65535u, VITMI_E_SHAPE, "gemm: M too large for the generic kernel grid");

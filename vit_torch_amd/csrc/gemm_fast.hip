@@ -247,6 +247,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
   const int nt_all = (int)(g.K / BK);
   const int kt0 = SPLITK ? split * ksps : 0;
   const int nt = SPLITK ? min(ksps, nt_all - kt0) : nt_all;
+  // diagnostic build of the timeline (armed by tools/gemm_phases.py only): entry,
+  // epilogue start and end of the first 64 blocks, wave 0
+  const bool dbg_tl = g.dbg != nullptr && blockIdx.x < 64 && wave == 0;
+  unsigned long long tl0 = 0;
+  if (dbg_tl) tl0 = stamp();
   if constexpr (PIPE == 0) {
   stage_tile<A_KM>(smem, A, g.lda, m0, (int64_t)kt0 * BK, wave, lane);
   stage_tile<B_KM>(smem + TILE_BYTES, B, g.ldb, n0, (int64_t)kt0 * BK, wave, lane);
@@ -430,6 +435,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
   // in order, so no barrier is needed) and then reads, post-processes and stores whole
   // rows: every global access of the epilogue (C, C2, R, AUX) is 16 B per lane and
   // covers full 128-B lines.
+  unsigned long long tl1 = 0;
+  if (dbg_tl) tl1 = stamp();
   constexpr int W = sizeof(TC) == 2 ? 8 : 4;       // columns per lane in the row pass
   constexpr int LPR = 64 / W;                      // lanes per 64-column row
   constexpr int RPI = 64 / LPR;                    // rows per wave instruction
@@ -446,6 +453,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
   constexpr int NJ = 16 / RPI;                     // row groups per strip
   const bool side = !SPLITK && epi_has_side<MODE, TC>(g.e);
   const int64_t ncol = n0 + wn * 64 + rc;
+  float cs[W];                                     // DGELU: column sums of this lane's rows
+#pragma unroll
+  for (int i = 0; i < W; ++i) cs[i] = 0.f;
   float sx[2][NJ][W];                              // side inputs: this strip and the next
 #pragma unroll
   for (int j = 0; j < NJ; ++j)
@@ -477,8 +487,33 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
       const int64_t m = m0 + wm * 128 + mi * 16 + row;
       if constexpr (SPLITK)
         storev<float, W>(ws + ((int64_t)split * g.M + m) * g.N + ncol, v);
-      else
+      else {
         epi_row<MODE, TC, W>(g.e, m, ncol, v, bias_r, gamma_r, sx[mi & 1][j]);
+        if constexpr (MODE == VITMI_EPI_DGELU) {
+#pragma unroll
+          for (int i = 0; i < W; ++i) cs[i] += v[i];
+        }
+      }
+    }
+  }
+  if constexpr (MODE == VITMI_EPI_DGELU && !SPLITK) {
+    if (g.e.colsum_part) {     // wave-uniform
+      // lanes rr = 0..RPI-1 hold the same W columns: fold them, lane rr = 0 stores the
+      // sums of this wave's 128 rows
+#pragma unroll
+      for (int i = 0; i < W; ++i) {
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1) cs[i] += __shfl_xor(cs[i], off, 64);
+      }
+      if (rr == 0) storev<float, W>(g.e.colsum_part + ((m0 >> 7) + wm) * g.N + ncol, cs);
+    }
+  }
+  if (dbg_tl) {
+    wait_vm(0);                                    // stores retired = the wave could end here
+    const unsigned long long tl2 = stamp();
+    if (lane == 0) {
+      g.dbg[64 + blockIdx.x * 4 + 0] = tl0; g.dbg[64 + blockIdx.x * 4 + 1] = tl1;
+      g.dbg[64 + blockIdx.x * 4 + 2] = tl2;
     }
   }
 }
@@ -624,6 +659,7 @@ static bool combo_built(const GemmArgs& g) {
 bool gemm_fast_supported(const GemmArgs& g, int in_bf16) {
   if (!in_bf16) return false;
   if (!use_tile2(g) && (g.M % BM || g.N % BN || g.K % BK)) return false;
+  if (g.e.colsum_part && (use_tile2(g) || g.e.mode != VITMI_EPI_DGELU || !is_aligned(g.e.colsum_part, 16))) return false;
   if (g.M / BM * (g.N / BN) > (1 << 30)) return false;
   if (!combo_built(g)) return false;
   const EpiArgs& e = g.e;

@@ -162,7 +162,8 @@ __device__ __forceinline__ void epi_row(const EpiArgs& e, int64_t m, int64_t n, 
       for (int i = 0; i < W; ++i) f[i] = v[i] + b[i];
       storev<bf16, W>(reinterpret_cast<bf16*>(e.C2) + m * e.ldc2 + n, f);
     }
-    const float rs = e.rowscale ? e.rowscale[m / e.rpg] : 1.f;
+    float rs = 1.f;
+    if (e.rowscale) rs = e.rowscale[(uint32_t)m / (uint32_t)e.rpg];      // uniform branch; M < 2^32
 #pragma unroll
     for (int i = 0; i < W; ++i) v[i] = x[i] + rs * gm[i] * (v[i] + b[i]);
   } else if constexpr (MODE == VITMI_EPI_DGELU) {

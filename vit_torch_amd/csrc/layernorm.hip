@@ -8,7 +8,10 @@ namespace {
 
 constexpr int LN_MAXV = 8;   // float4 chunks per lane -> D <= 8*64*4 = 2048
 
-template <typename TX, typename TY>
+// NV = float4 chunks per lane actually instantiated (D <= NV*256): the row lives in
+// registers, so a D = 768 row must not pay for the 2048-wide case's registers (occupancy
+// is what hides the HBM latency here).
+template <int NV, typename TX, typename TY>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, int64_t xs,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ beta,
@@ -19,10 +22,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, i
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < M; row += (int64_t)gridDim.x * 4) {
   const TX* xr = x + row * xs;
-  f32x4 v[LN_MAXV];
+  f32x4 v[NV];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * 4;
     if (c < D) {
       v[i] = load4<TX>(xr + c);
@@ -32,7 +35,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, i
   const float mean = wave_sum(s) / (float)D;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * 4;
     if (c < D) {
 #pragma unroll
@@ -47,7 +50,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, i
   }
   TY* yr = y + row * ys;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * 4;
     if (c < D) {
       const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, i
 // [2D..3D) = column sum of g_out (the bias gradient of the Linear that produced this
 // LayerNorm's input: it costs three adds per element here instead of a separate pass over
 // g_out).  reduce_rows sums the partial rows.
-template <typename TDY, typename TX, typename TG, typename TGB>
+template <int NV, typename TDY, typename TX, typename TG, typename TGB>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy, int64_t dys,
                                                      const TX* __restrict__ x, int64_t xs,
                                                      const float* __restrict__ mean,
@@ -81,27 +84,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
                                                      int64_t M, int D) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [4][D]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  f32x4 gam[LN_MAXV], dg[LN_MAXV], db[LN_MAXV], gs[LN_MAXV], gsc[LN_MAXV];
+  f32x4 gam[NV], dg[NV], db[NV], gs[NV];
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * 4;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 one = {1.f, 1.f, 1.f, 1.f};
-    dg[i] = z; db[i] = z; gam[i] = z; gs[i] = z; gsc[i] = one;
-    if (c < D) {
-      gam[i] = *reinterpret_cast<const f32x4*>(gamma + c);
-      if (gb_scale) gsc[i] = *reinterpret_cast<const f32x4*>(gb_scale + c);
-    }
+    dg[i] = z; db[i] = z; gam[i] = z; gs[i] = z;
+    if (c < D) gam[i] = *reinterpret_cast<const f32x4*>(gamma + c);
   }
   const float invD = 1.f / (float)D;
   for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < M; row += (int64_t)gridDim.x * 4) {
     const float mu = mean[row], rs = rstd[row];
     const TDY* dyr = dy + row * dys;
     const TX* xr = x + row * xs;
-    f32x4 xh[LN_MAXV], dv[LN_MAXV];
+    f32x4 xh[NV], dv[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 4;
       if (c < D) {
         const f32x4 xv = load4<TX>(xr + c);
@@ -118,9 +117,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
       }
     }
     const float c1 = wave_sum(s1) * invD, c2 = wave_sum(s2) * invD;
-    const float rsc = gb_rowscale ? gb_rowscale[row / rpg] : 1.f;
+    float rsc = 1.f;
+    if (gb_rowscale) rsc = gb_rowscale[(uint32_t)row / (uint32_t)rpg];   // wave-uniform branch; M < 2^32
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 4;
       if (c < D) {
         f32x4 o;
@@ -134,8 +134,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
         store4<TG>(g_out + row * gstride + c, o);
         // the GEMM-operand copy (and its column sum) carry the LayerScale of the branch
         // that will consume them: d(branch out) = g_out * gamma_branch
+        // (gb_scale is re-read per row, from L1: holding it would cost NV*4 registers
+        // and a wave of occupancy on a kernel that lives on memory-level parallelism)
+        if (gb_scale) {
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(gb_scale + c);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] *= gsc[i][j] * rsc;
+          for (int j = 0; j < 4; ++j) o[j] *= sc[j];
+        }
+        if (gb_rowscale) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] *= rsc;
+        }
         if (gb_out) store4<TGB>(gb_out + row * gbs + c, o);
 #pragma unroll
         for (int j = 0; j < 4; ++j) gs[i][j] += o[j];
@@ -147,7 +156,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
 #pragma unroll 1
   for (int pass = 0; pass < (want_gsum ? 3 : 2); ++pass) {
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 4;
       if (c < D) *reinterpret_cast<f32x4*>(red + w * D + c) = pass == 0 ? dg[i] : (pass == 1 ? db[i] : gs[i]);
     }
@@ -158,9 +167,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
   }
 }
 
-inline int ln_bwd_blocks(int64_t M) {
+inline int ln_nv(int64_t D) { return D <= 512 ? 2 : D <= 768 ? 3 : D <= 1024 ? 4 : LN_MAXV; }
+// grid-stride blocks of the backward kernel: 4 per CU while the row fits few registers
+inline int ln_bwd_blocks(int64_t M, int64_t D) {
+  // resident blocks per CU by the kernels' register counts (102 / 132 / 162 / 256+ VGPRs)
+  const int nv = ln_nv(D);
+  const int64_t cap = nv == 2 ? 1024 : nv <= 4 ? 768 : 512;
   int64_t b = (M + 3) / 4;
-  return (int)(b < 512 ? b : 512);
+  return (int)(b < cap ? b : cap);
 }
 
 }  // namespace
@@ -187,20 +201,30 @@ extern "C" int vitmi_layernorm_fwd(const void* x, int x_dtype, int64_t x_stride,
   int64_t nblk = (M + 3) / 4;
   if (nblk > 2048) nblk = 2048;
   dim3 grid((unsigned)nblk), block(256);
-#define LN_FWD(TX, TY)                                                                        \
-  hipLaunchKernelGGL((ln_fwd_kernel<TX, TY>), grid, block, 0, stream, (const TX*)x, x_stride, \
+#define LN_FWD_NV(NVV, TX, TY)                                                                     \
+  hipLaunchKernelGGL((ln_fwd_kernel<NVV, TX, TY>), grid, block, 0, stream, (const TX*)x, x_stride, \
                      gamma, beta, (TY*)y, y_stride, mean, rstd, M, (int)D, eps)
+#define LN_FWD(TX, TY)                                                                        \
+  do {                                                                                        \
+    switch (ln_nv(D)) {                                                                       \
+      case 2: LN_FWD_NV(2, TX, TY); break;                                                    \
+      case 3: LN_FWD_NV(3, TX, TY); break;                                                    \
+      case 4: LN_FWD_NV(4, TX, TY); break;                                                    \
+      default: LN_FWD_NV(LN_MAXV, TX, TY); break;                                             \
+    }                                                                                         \
+  } while (0)
   if (x_dtype == VITMI_F32 && y_dtype == VITMI_F32) LN_FWD(float, float);
   else if (x_dtype == VITMI_F32 && y_dtype == VITMI_BF16) LN_FWD(float, bf16);
   else if (x_dtype == VITMI_BF16 && y_dtype == VITMI_BF16) LN_FWD(bf16, bf16);
   else if (x_dtype == VITMI_BF16 && y_dtype == VITMI_F32) LN_FWD(bf16, float);
   else return vitmi_fail(VITMI_E_DTYPE, "layernorm_fwd: dtype combination");
 #undef LN_FWD
+#undef LN_FWD_NV
   return vitmi_check_launch("ln_fwd_kernel");
 }
 
 extern "C" size_t vitmi_layernorm_bwd_workspace(int64_t M, int64_t D) {
-  return (size_t)ln_bwd_blocks(M) * 3 * (size_t)D * sizeof(float);
+  return (size_t)ln_bwd_blocks(M, D) * 3 * (size_t)D * sizeof(float);
 }
 
 extern "C" int vitmi_layernorm_bwd(const void* dy, int dy_dtype, int64_t dy_stride, const void* x,
@@ -214,6 +238,7 @@ extern "C" int vitmi_layernorm_bwd(const void* dy, int dy_dtype, int64_t dy_stri
   int rc = check_ln_common(x, x_dtype, x_stride, M, D, "layernorm_bwd");
   if (rc) return rc;
   VITMI_REQUIRE(dy && mean && rstd && gamma && g_out && dgamma && dbeta, VITMI_E_BADARG, "layernorm_bwd: null argument");
+  VITMI_REQUIRE(!gb_rowscale || (M < (1ll << 32) && rows_per_group < (1ll << 32)), VITMI_E_SHAPE, "layernorm_bwd: gb_rowscale needs M < 2^32");
   VITMI_REQUIRE(dy_stride % 4 == 0 && g_stride % 4 == 0 && (!gb_out || gb_stride % 4 == 0), VITMI_E_ALIGN, "layernorm_bwd: strides must be multiples of 4");
   VITMI_REQUIRE(is_aligned(dy, 4 * dtype_size(dy_dtype)) && is_aligned(g_out, 4 * dtype_size(g_dtype)) &&
                     (!g_in || is_aligned(g_in, 4 * dtype_size(g_dtype))) &&
@@ -222,16 +247,25 @@ extern "C" int vitmi_layernorm_bwd(const void* dy, int dy_dtype, int64_t dy_stri
   VITMI_REQUIRE(workspace && workspace_bytes >= vitmi_layernorm_bwd_workspace(M, D), VITMI_E_WORKSPACE, "layernorm_bwd: workspace too small");
   VITMI_REQUIRE(is_aligned(workspace, 16), VITMI_E_ALIGN, "layernorm_bwd: workspace alignment");
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  const int nblk = ln_bwd_blocks(M);
+  const int nblk = ln_bwd_blocks(M, D);
   const size_t lds = 4 * (size_t)D * sizeof(float);
   float* part = reinterpret_cast<float*>(workspace);
   // activation dtype T (dy, gb) and residual dtype R (x, g) combinations built:
   //   (T,R) = (f32,f32), (bf16,f32), (bf16,bf16)
-#define LN_BWD(TDY, TX, TG, TGB)                                                               \
-  hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TG, TGB>), dim3(nblk), dim3(256), lds, stream,    \
+#define LN_BWD_NV(NVV, TDY, TX, TG, TGB)                                                       \
+  hipLaunchKernelGGL((ln_bwd_kernel<NVV, TDY, TX, TG, TGB>), dim3(nblk), dim3(256), lds, stream, \
                      (const TDY*)dy, dy_stride, (const TX*)x, x_stride, mean, rstd, gamma,     \
-                     (const TG*)g_in, (TG*)g_out, g_stride, (TGB*)gb_out, gb_stride, part, gsum ? 1 : 0, gb_scale, gb_rowscale,       \
-                     rows_per_group > 0 ? rows_per_group : 1, M, (int)D)
+                     (const TG*)g_in, (TG*)g_out, g_stride, (TGB*)gb_out, gb_stride, part,     \
+                     gsum ? 1 : 0, gb_scale, gb_rowscale, rows_per_group > 0 ? rows_per_group : 1, M, (int)D)
+#define LN_BWD(TDY, TX, TG, TGB)                                                               \
+  do {                                                                                         \
+    switch (ln_nv(D)) {                                                                        \
+      case 2: LN_BWD_NV(2, TDY, TX, TG, TGB); break;                                           \
+      case 3: LN_BWD_NV(3, TDY, TX, TG, TGB); break;                                           \
+      case 4: LN_BWD_NV(4, TDY, TX, TG, TGB); break;                                           \
+      default: LN_BWD_NV(LN_MAXV, TDY, TX, TG, TGB); break;                                    \
+    }                                                                                          \
+  } while (0)
   const int gbd = gb_out ? gb_dtype : dy_dtype;
   if (dy_dtype == VITMI_F32 && x_dtype == VITMI_F32 && g_dtype == VITMI_F32 && gbd == VITMI_F32) LN_BWD(float, float, float, float);
   else if (dy_dtype == VITMI_BF16 && x_dtype == VITMI_F32 && g_dtype == VITMI_F32 && gbd == VITMI_BF16) LN_BWD(bf16, float, float, bf16);
@@ -241,6 +275,7 @@ extern "C" int vitmi_layernorm_bwd(const void* dy, int dy_dtype, int64_t dy_stri
   else if (dy_dtype == VITMI_F32 && x_dtype == VITMI_BF16 && g_dtype == VITMI_BF16 && gbd == VITMI_BF16) LN_BWD(float, bf16, bf16, bf16);
   else return vitmi_fail(VITMI_E_DTYPE, "layernorm_bwd: dtype combination (dy=%d x=%d g=%d gb=%d)", dy_dtype, x_dtype, g_dtype, gbd);
 #undef LN_BWD
+#undef LN_BWD_NV
   rc = vitmi_check_launch("ln_bwd_kernel");
   if (rc) return rc;
   rc = vitmi_reduce_rows(part, nblk, D, 3 * D, dgamma, stream);

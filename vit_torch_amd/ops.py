@@ -51,7 +51,7 @@ def workspace(nbytes: int, device) -> torch.Tensor:
 
 def gemm(A, B, C_out, *, a_kmajor=True, b_kmajor=True, epilogue=EPI_STORE, bias=None, R=None,
          gamma=None, aux=None, C2=None, pos=None, n_tok=0, cls=None, alpha=1.0, accumulate=False,
-         impl=GEMM_AUTO, rowscale=None, rows_per_group=0):
+         impl=GEMM_AUTO, rowscale=None, rows_per_group=0, colsum_part=None):
     """C = epilogue(op(A) @ op(B)^T); see vitmi_gemm in include/vitmi.h."""
     _need_cuda(A, B, C_out)
     assert A.dim() == 2 and B.dim() == 2 and C_out.dim() == 2
@@ -96,6 +96,10 @@ def gemm(A, B, C_out, *, a_kmajor=True, b_kmajor=True, epilogue=EPI_STORE, bias=
     if rowscale is not None:
         assert rowscale.dtype == torch.float32 and rows_per_group > 0 and rowscale.numel() * rows_per_group >= M
         d.rowscale, d.rows_per_group = rowscale.data_ptr(), rows_per_group
+    if colsum_part is not None:
+        assert colsum_part.dtype == torch.float32 and colsum_part.is_contiguous()
+        assert tuple(colsum_part.shape) == (M // 128, N) and M % 128 == 0
+        d.colsum_part = colsum_part.data_ptr()
     lib = load()
     need = lib.vitmi_gemm_workspace(C.byref(d))
     if need:
@@ -129,7 +133,7 @@ def gemm_batched(A, B, C_out, *, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, bat
 
 
 def gemm_uses_fast(M, N, K, *, a_kmajor=True, b_kmajor=True, in_dtype=BF16, c_dtype=BF16,
-                   epilogue=EPI_STORE, lda=None, ldb=None, ldc=None) -> bool:
+                   epilogue=EPI_STORE, lda=None, ldb=None, ldc=None, colsum_part=False) -> bool:
     """Host-only query (no GPU needed): would this problem take the fast kernel?"""
     d = GemmDesc()
     d.M, d.N, d.K = M, N, K
@@ -142,6 +146,8 @@ def gemm_uses_fast(M, N, K, *, a_kmajor=True, b_kmajor=True, in_dtype=BF16, c_dt
     d.n_tok = 1
     d.a_kmajor, d.b_kmajor = int(a_kmajor), int(b_kmajor)
     d.in_dtype, d.c_dtype, d.r_dtype, d.epilogue = in_dtype, c_dtype, c_dtype, epilogue
+    if colsum_part:
+        d.colsum_part = 256
     return bool(load().vitmi_gemm_uses_fast(C.byref(d)))
 
 
@@ -187,13 +193,21 @@ def attn_fwd(qkv, out, lse, B, N, H, hd, scale):
     return out
 
 
-def attn_bwd(qkv, out, dout, lse, dqkv, B, N, H, hd, scale):
+def attn_bwd_dbias_rows(B, N) -> int:
+    return int(load().vitmi_attn_bwd_dbias_rows(B, N))
+
+
+def attn_bwd(qkv, out, dout, lse, dqkv, B, N, H, hd, scale, dbias_part=None):
+    """dbias_part (bf16 only): fp32 [attn_bwd_dbias_rows(B, N), 3*H*hd] partial column sums of dqkv."""
     _need_cuda(qkv, out, dout, dqkv)
     assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and dqkv.is_contiguous()
     lib = load()
+    if dbias_part is not None:
+        assert dbias_part.dtype == torch.float32 and dbias_part.is_contiguous()
+        assert tuple(dbias_part.shape) == (attn_bwd_dbias_rows(B, N), 3 * H * hd)
     ws = workspace(lib.vitmi_attn_bwd_workspace(B, N, H), qkv.device)
     check(lib.vitmi_attn_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
-                             dqkv.data_ptr(), dtype_code(qkv), B, N, H, hd, float(scale),
+                             dqkv.data_ptr(), dtype_code(qkv), B, N, H, hd, float(scale), _ptr(dbias_part),
                              ws.data_ptr(), ws.numel(), _stream()), "vitmi_attn_bwd")
     return dqkv
 
