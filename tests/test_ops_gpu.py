@@ -249,9 +249,23 @@ ATTN_CASES = [(2, 197, 3, 64), (3, 5, 2, 64), (1, 145, 2, 64), (2, 49, 3, 32), (
               (2, 64, 2, 32), (1, 785, 1, 64), (1, 1, 1, 64)]
 
 
+@pytest.fixture(params=["fused", "split"])
+def attn_bwd_mode(request, lib):
+    """bf16 attention backward: one workgroup per (image, head) with dQ in LDS (N <= 256),
+    or the dkdv + dq kernel pair; the fp32 kernels ignore the switch."""
+    import ctypes
+    from vit_torch_amd import _lib
+    raw = ctypes.CDLL(str(_lib.LIB_PATH))
+    raw.vitmi_debug_attn_bwd(1 if request.param == "fused" else 0)
+    yield request.param
+    raw.vitmi_debug_attn_bwd(-1)
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,N,H,hd", ATTN_CASES)
-def test_attention_fwd_bwd(ops, dt, B, N, H, hd):
+@pytest.mark.parametrize("B,N,H,hd", ATTN_CASES + [(2, 224, 2, 64), (1, 256, 2, 64), (2, 256, 1, 32), (1, 33, 1, 32)])
+def test_attention_fwd_bwd(ops, attn_bwd_mode, dt, B, N, H, hd):
+    if dt == torch.float32 and attn_bwd_mode == "split":
+        pytest.skip("fp32 kernels have one backward path")
     scale = hd ** -0.5
     qkv = gen((B, N, 3 * H * hd), 1)
     do = gen((B, N, H * hd), 2)

@@ -1,0 +1,40 @@
+"""Micro-benchmark of the fused attention kernels on the ViT-B/16 bs256 shape (or B:N:H:hd args)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vit_torch_amd import ops  # noqa: E402
+
+specs = sys.argv[1:] or ["256:197:12:64"]
+for spec in specs:
+    B, N, H, hd = map(int, spec.split(":"))
+    D = H * hd
+    qkv = (torch.randn(B, N, 3 * D, device="cuda") * 0.5).to(torch.bfloat16)
+    do = torch.randn(B, N, D, device="cuda").to(torch.bfloat16)
+    O = torch.empty_like(do)
+    lse = torch.empty(B * H * N, device="cuda")
+    dqkv = torch.empty_like(qkv)
+    part = torch.empty((ops.attn_bwd_dbias_rows(B, N), 3 * D), device="cuda")
+    scale = hd ** -0.5
+
+    def timed(fn, n=20):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e3
+
+    import ctypes
+    from vit_torch_amd import _lib
+    raw = ctypes.CDLL(str(_lib.LIB_PATH))
+    fl = 4.0 * B * H * N * N * hd
+    tf = timed(lambda: ops.attn_fwd(qkv, O, lse, B, N, H, hd, scale))
+    print(f"{spec}: fwd {tf:7.1f} us ({fl / tf / 1e6:6.1f} TF)")
+    for rnd in range(2):                     # interleaved rounds, one process (guide rule 24)
+        for mode, name in ((0, "split"), (1, "fused")):
+            raw.vitmi_debug_attn_bwd(mode)
+            tb = timed(lambda: ops.attn_bwd(qkv, O, do, lse, dqkv, B, N, H, hd, scale, dbias_part=part))
+            print(f"   bwd[{name}] {tb:7.1f} us ({2.5 * fl / tb / 1e6:6.1f} TF)")
+    raw.vitmi_debug_attn_bwd(-1)

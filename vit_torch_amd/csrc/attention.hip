@@ -525,6 +525,232 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
   }
 }
 
+
+// ------------------------------------- backward, whole sequence in one CU ---
+// For N <= 256 one workgroup holds Q, dO and the fp32 dQ of a whole (image, head) in LDS
+// and wave w owns key block w (K and V rows in registers): FIVE products per
+// (query block, key block) pair instead of the seven of the dkdv + dq pair, one exp per
+// score instead of two, no delta kernel (rowsum(dO*O) is taken while dO is staged).
+//   S = Q K^T, dP = dO V^T           key on the lane (as in dkdv)
+//   dV^T += dO^T P, dK^T += Q^T dS   accumulators stay in registers (own keys)
+//   dQ^T(j) += K^T dS^T              dS goes through a wave-private 2-KiB LDS tile
+//                                    [key][q] and comes back transposed (ds_read_b64_tr_b16)
+// dQ of query block j is summed over the waves: at step t wave w works on query block
+// (w + t) mod nw, so no two waves touch the same dQ block in a step and a plain LDS
+// read-modify-write between two barriers is exact and in a fixed order (deterministic).
+template <int HD> struct FusedBwdCfg {
+  static constexpr int QS = AttnCfg<HD>::KS;     // staged Q / dO / K row (bytes)
+  static constexpr int DQS = HD * 4 + 16;        // fp32 dQ row (bytes)
+  static constexpr int ROW_BYTES = 2 * QS + DQS + 8 + 64;   // + lse, delta, dS tile share
+};
+
+template <int HD, bool DBIAS>
+__global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16* __restrict__ qkv,
+                                                             const bf16* __restrict__ out,
+                                                             const bf16* __restrict__ dout,
+                                                             const float* __restrict__ lse,
+                                                             bf16* __restrict__ dqkv, int N, int H,
+                                                             float scale, float scale_log2e,
+                                                             float* __restrict__ dbias_part) {
+  using C = AttnCfg<HD>;
+  using F = FusedBwdCfg<HD>;
+  constexpr int QS = F::QS, DQS = F::DQS, CPR = HD / 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
+  const int lr = lane & 31, h5 = lane >> 5;
+  const int NP = nw * 32;
+  char* Ql = smem;
+  char* dOl = Ql + NP * QS;
+  char* dQl = dOl + NP * QS;                       // first the K staging, then fp32 dQ
+  float* lse_s = reinterpret_cast<float*>(dQl + NP * DQS);
+  float* del_s = lse_s + NP;
+  char* Tl = reinterpret_cast<char*>(del_s + NP) + w * 2048;
+  const int bh = blockIdx.x, b = bh / H, h = bh % H;
+  const int64_t ts = (int64_t)3 * H * HD;
+  const int64_t os = (int64_t)H * HD;
+  const bf16* qb = qkv + (int64_t)b * N * ts + h * HD;
+  const bf16* kb_ = qb + H * HD;
+  const bf16* vb = qb + 2 * H * HD;
+  const bf16* dob = dout + (int64_t)b * N * os + h * HD;
+  const bf16* ob = out + (int64_t)b * N * os + h * HD;
+  const int key = w * 32 + lr;
+  const int krow = min(key, N - 1);
+
+  bf16x8 vf[C::KSTEPS];                            // B[k = d][n = key] of dP = dO V^T
+#pragma unroll
+  for (int s = 0; s < C::KSTEPS; ++s)
+    vf[s] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)krow * ts + 16 * s + 8 * h5);
+
+  // ---- stage Q, dO (and delta = rowsum(dO * O)), K; rows >= N are zero
+  for (int c = tid; c < NP * CPR; c += nthr) {
+    const int row = c / CPR, pc = c % CPR;
+    bf16x8 q8, d8, o8, k8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { q8[e] = (bf16)0.f; d8[e] = (bf16)0.f; o8[e] = (bf16)0.f; k8[e] = (bf16)0.f; }
+    if (row < N) {
+      q8 = *reinterpret_cast<const bf16x8*>(qb + (int64_t)row * ts + pc * 8);
+      k8 = *reinterpret_cast<const bf16x8*>(kb_ + (int64_t)row * ts + pc * 8);
+      d8 = *reinterpret_cast<const bf16x8*>(dob + (int64_t)row * os + pc * 8);
+      o8 = *reinterpret_cast<const bf16x8*>(ob + (int64_t)row * os + pc * 8);
+    }
+    *reinterpret_cast<bf16x8*>(Ql + row * QS + pc * 16) = q8;
+    *reinterpret_cast<bf16x8*>(dOl + row * QS + pc * 16) = d8;
+    *reinterpret_cast<bf16x8*>(dQl + row * QS + pc * 16) = k8;
+    float dot = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dot = fmaf((float)d8[e], (float)o8[e], dot);
+#pragma unroll
+    for (int off = 1; off < CPR; off <<= 1) dot += __shfl_xor(dot, off, 64);   // CPR consecutive lanes = one row
+    if (pc == 0) {
+      del_s[row] = dot;
+      lse_s[row] = row < N ? lse[(int64_t)bh * N + row] * LOG2E : INFINITY;    // +inf -> p = 0 for padded queries
+    }
+  }
+  __syncthreads();
+  bf16x8 kf[C::KSTEPS];                            // B[k = d][n = key] of S = Q K^T
+#pragma unroll
+  for (int s = 0; s < C::KSTEPS; ++s)
+    kf[s] = *reinterpret_cast<const bf16x8*>(dQl + key * QS + (16 * s + 8 * h5) * 2);
+  bf16x8 kT[2][C::DB];                             // A[m = d][k = key] of dQ^T += K^T dS^T
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int db = 0; db < C::DB; ++db) kT[s2][db] = load_tr_frag(dQl, QS, w * 32 + 16 * s2, db * 32, lane);
+  __syncthreads();                                 // K staging consumed: the region becomes dQ
+  {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (int c = tid; c < NP * DQS / 16; c += nthr) *reinterpret_cast<f32x4*>(dQl + c * 16) = z;
+  }
+  __syncthreads();
+
+  f32x16 dk[C::DB], dv[C::DB];
+#pragma unroll
+  for (int db = 0; db < C::DB; ++db) { zero16(dk[db]); zero16(dv[db]); }
+  const bool kvalid = key < N;
+
+#pragma unroll 1
+  for (int t = 0; t < nw; ++t) {
+    int j = w + t;
+    if (j >= nw) j -= nw;
+    f32x16 s, dp;
+    zero16(s);
+    zero16(dp);
+#pragma unroll
+    for (int ks = 0; ks < C::KSTEPS; ++ks) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ql + (j * 32 + lr) * QS + (16 * ks + 8 * h5) * 2);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf[ks], s, 0, 0, 0);
+    }
+#pragma unroll
+    for (int ks = 0; ks < C::KSTEPS; ++ks) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(dOl + (j * 32 + lr) * QS + (16 * ks + 8 * h5) * 2);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, vf[ks], dp, 0, 0, 0);
+    }
+    // rows = query inside the block (runs of 4: 8*g + 4*h5 + e), lane = key
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 ls = *reinterpret_cast<const f32x4*>(lse_s + j * 32 + 8 * g + 4 * h5);
+      const f32x4 de = *reinterpret_cast<const f32x4*>(del_s + j * 32 + 8 * g + 4 * h5);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        float p = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -ls[e]));
+        p = kvalid ? p : 0.f;                      // zero-filled K rows give p = exp(-lse) != 0
+        s[r] = p;
+        dp[r] = p * (dp[r] - de[e]);
+      }
+    }
+    // dS -> wave-private tile T[key][q] (bf16), 4 consecutive queries per store
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 o4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o4[e] = (bf16)dp[4 * g + e];
+      *reinterpret_cast<bf16x4*>(Tl + lr * 64 + (8 * g + 4 * h5) * 2) = o4;
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const bf16x8 pf = pack8(s, 8 * s2);
+      const bf16x8 dsf = pack8(dp, 8 * s2);
+#pragma unroll
+      for (int db = 0; db < C::DB; ++db) {
+        const bf16x8 a = load_tr_frag(dOl, QS, j * 32 + 16 * s2, db * 32, lane);
+        dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf, dv[db], 0, 0, 0);
+        const bf16x8 a2 = load_tr_frag(Ql, QS, j * 32 + 16 * s2, db * 32, lane);
+        dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, dsf, dk[db], 0, 0, 0);
+      }
+    }
+    // dQ^T(j)[d][q] += K^T[d][key] dS^T[key][q]; accumulator rows d = db*32 + 8*g + 4*h5 + e
+    {
+      char* dqrow = dQl + (j * 32 + lr) * DQS + 16 * h5;
+      f32x16 dq[C::DB];
+#pragma unroll
+      for (int db = 0; db < C::DB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(dqrow + (db * 32 + 8 * g) * 4);
+          dq[db][4 * g] = v[0]; dq[db][4 * g + 1] = v[1]; dq[db][4 * g + 2] = v[2]; dq[db][4 * g + 3] = v[3];
+        }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 bT = load_tr_frag(Tl, 64, 16 * s2, 0, lane);
+#pragma unroll
+        for (int db = 0; db < C::DB; ++db)
+          dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT[s2][db], bT, dq[db], 0, 0, 0);
+      }
+#pragma unroll
+      for (int db = 0; db < C::DB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 v = {dq[db][4 * g], dq[db][4 * g + 1], dq[db][4 * g + 2], dq[db][4 * g + 3]};
+          *reinterpret_cast<f32x4*>(dqrow + (db * 32 + 8 * g) * 4) = v;
+        }
+    }
+    __syncthreads();                               // the dQ blocks change hands
+  }
+
+  if (kvalid) {
+    bf16* row = dqkv + (int64_t)(b * (int64_t)N + key) * ts + h * HD;
+    store_T_tile<HD>(row + H * HD, dk, scale, h5);
+    store_T_tile<HD>(row + 2 * H * HD, dv, 1.f, h5);
+  }
+  // dQ: fp32 LDS rows -> scaled bf16, 16-B pieces, coalesced
+  for (int c = tid; c < N * CPR; c += nthr) {
+    const int row = c / CPR, pc = c % CPR;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(dQl + row * DQS + pc * 32);
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(dQl + row * DQS + pc * 32 + 16);
+    bf16x8 o8;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o8[e] = (bf16)(a[e] * scale); o8[4 + e] = (bf16)(b4[e] * scale); }
+    *reinterpret_cast<bf16x8*>(dqkv + (int64_t)(b * (int64_t)N + row) * ts + h * HD + pc * 8) = o8;
+  }
+  if constexpr (DBIAS) {
+    // column sums of dQ / dK / dV of this (image, head): the qkv-bias gradient partials
+    float* red = reinterpret_cast<float*>(Ql);     // Q / dO are dead after the last barrier
+    colsum_T_tile<HD>(red + (w * 2 + 0) * HD, dk, scale, kvalid, lr, h5);
+    colsum_T_tile<HD>(red + (w * 2 + 1) * HD, dv, 1.f, kvalid, lr, h5);
+    float* redq = red + nw * 2 * HD;
+    const int P = nthr / HD;
+    {
+      const int col = tid % HD, part = tid / HD;
+      float t = 0.f;
+      for (int row = part; row < N; row += P) t += *reinterpret_cast<const float*>(dQl + row * DQS + col * 4);
+      redq[part * HD + col] = t * scale;
+    }
+    __syncthreads();
+    for (int i = tid; i < 3 * HD; i += nthr) {
+      const int which = i / HD, d = i % HD;
+      float t = 0.f;
+      if (which == 0) {
+        for (int pp = 0; pp < P; ++pp) t += redq[pp * HD + d];
+      } else {
+        for (int ww = 0; ww < nw; ++ww) t += red[(ww * 2 + which - 1) * HD + d];
+      }
+      dbias_part[(int64_t)b * ts + which * H * HD + h * HD + d] = t;
+    }
+  }
+}
+
 inline int attn_waves(int64_t N) {
   int64_t nw = ((N < 256 ? N : 256) + 31) / 32;
   return (int)(nw < 1 ? 1 : nw);
@@ -568,6 +794,15 @@ extern "C" size_t vitmi_attn_bwd_workspace(int64_t B, int64_t N, int64_t H) {
   return (size_t)(B * N * H) * sizeof(float);
 }
 
+static int g_attn_bwd_mode = -1;     // diagnostic / test hook: 0 = dkdv + dq kernels, 1 = fused where possible
+extern "C" void vitmi_debug_attn_bwd(int mode) { g_attn_bwd_mode = mode; }
+static bool attn_bwd_fused_ok(int64_t N, int64_t hd) {
+  if (g_attn_bwd_mode == 0) return false;
+  const int nw = attn_waves(N);
+  const size_t lds = (size_t)nw * 32 * (hd == 64 ? FusedBwdCfg<64>::ROW_BYTES : FusedBwdCfg<32>::ROW_BYTES);
+  return N <= 256 && lds <= 160 * 1024;
+}
+
 extern "C" int64_t vitmi_attn_bwd_dbias_rows(int64_t B, int64_t N) {
   const int nw = attn_waves(N);
   return B * ((N + 32 * nw - 1) / (32 * nw));
@@ -589,6 +824,27 @@ extern "C" int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout
   VITMI_REQUIRE(is_aligned(out, 16) && is_aligned(dout, 16) && is_aligned(dqkv, 8), VITMI_E_ALIGN, "attn_bwd: out/dout must be 16-B, dqkv 8-B aligned");
   const int64_t rows = B * N * H;
   const int nw = attn_waves(N);
+  if (attn_bwd_fused_ok(N, hd)) {
+#define LAUNCH_FUSED(HDV, DB)                                                                            \
+    do {                                                                                                 \
+      auto kern = attn_bwd_fused_kernel<HDV, DB>;                                                        \
+      const size_t lds = (size_t)nw * 32 * FusedBwdCfg<HDV>::ROW_BYTES;                                  \
+      static bool attr_set = false;                                                                      \
+      if (!attr_set) {                                                                                   \
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                        \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);    \
+        if (err != hipSuccess) return vitmi_fail((int)err, "attn_bwd: cannot raise dynamic LDS: %s", hipGetErrorString(err)); \
+        attr_set = true;                                                                                 \
+      }                                                                                                  \
+      hipLaunchKernelGGL(kern, dim3((unsigned)(B * H)), dim3(64 * nw), lds, stream, (const bf16*)qkv,    \
+                         (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, (int)N, (int)H, scale,   \
+                         scale * LOG2E, dbias_part);                                                     \
+    } while (0)
+    if (hd == 64) { if (dbias_part) LAUNCH_FUSED(64, true); else LAUNCH_FUSED(64, false); }
+    else          { if (dbias_part) LAUNCH_FUSED(32, true); else LAUNCH_FUSED(32, false); }
+#undef LAUNCH_FUSED
+    return vitmi_check_launch("attn_bwd_fused_kernel");
+  }
   dim3 grid((unsigned)((N + 32 * nw - 1) / (32 * nw)), (unsigned)(B * H));
 #define LAUNCH_BWD(HDV, DB)                                                                              \
   do {                                                                                                   \

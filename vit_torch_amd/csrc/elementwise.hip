@@ -131,6 +131,29 @@ __global__ __launch_bounds__(1024) void reduce_rows_kernel(const float* __restri
   }
 }
 
+// the same for up to three N-wide column segments of one partial buffer, each with its own
+// destination (LayerNorm backward: dgamma | dbeta | column sum), in one launch
+__global__ __launch_bounds__(1024) void reduce_rows3_kernel(const float* __restrict__ part, int S,
+                                                            int64_t N, int64_t ld, float* out0,
+                                                            float* out1, float* out2) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int seg = blockIdx.y;
+  float* out = seg == 0 ? out0 : (seg == 1 ? out1 : out2);
+  const int64_t c = (int64_t)blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (c < N)
+    for (int r = w; r < S; r += 16) s += part[(int64_t)r * ld + seg * N + c];
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && c < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][lane];
+    out[c] = t;
+  }
+}
+
 inline int colsum_splits(int64_t M) {
   int64_t s = (M + 3) / 4;
   return (int)(s < 128 ? s : 128);
@@ -227,6 +250,14 @@ __global__ void sgd_momentum_kernel(float* __restrict__ p, const float* __restri
 }
 
 }  // namespace
+
+int vitmi_reduce_rows3(const float* part, int S, int64_t N, int64_t ld, float* out0, float* out1, float* out2,
+                       hipStream_t stream) {
+  const unsigned segs = out2 ? 3 : 2;
+  hipLaunchKernelGGL(reduce_rows3_kernel, dim3((unsigned)((N + 63) / 64), segs), dim3(1024), 0, stream, part, S,
+                     N, ld, out0, out1, out2);
+  return vitmi_check_launch("reduce_rows3_kernel");
+}
 
 int vitmi_reduce_rows(const float* part, int S, int64_t N, int64_t ld, float* out, hipStream_t stream) {
   hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((N + 63) / 64)), dim3(1024), 0, stream, part, S, N, ld, out);

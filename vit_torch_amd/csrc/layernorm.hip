@@ -278,9 +278,5 @@ extern "C" int vitmi_layernorm_bwd(const void* dy, int dy_dtype, int64_t dy_stri
 #undef LN_BWD_NV
   rc = vitmi_check_launch("ln_bwd_kernel");
   if (rc) return rc;
-  rc = vitmi_reduce_rows(part, nblk, D, 3 * D, dgamma, stream);
-  if (rc) return rc;
-  rc = vitmi_reduce_rows(part + D, nblk, D, 3 * D, dbeta, stream);
-  if (rc || !gsum) return rc;
-  return vitmi_reduce_rows(part + 2 * D, nblk, D, 3 * D, gsum, stream);
+  return vitmi_reduce_rows3(part, nblk, D, 3 * D, dgamma, dbeta, gsum, stream);
 }
