@@ -30,11 +30,25 @@ for spec in specs:
     from vit_torch_amd import _lib
     raw = ctypes.CDLL(str(_lib.LIB_PATH))
     fl = 4.0 * B * H * N * N * hd
-    tf = timed(lambda: ops.attn_fwd(qkv, O, lse, B, N, H, hd, scale))
-    print(f"{spec}: fwd {tf:7.1f} us ({fl / tf / 1e6:6.1f} TF)")
+    for cap in (8, 4, 8, 4):
+        raw.vitmi_debug_attn_fwd_waves(cap)
+        tf = timed(lambda: ops.attn_fwd(qkv, O, lse, B, N, H, hd, scale))
+        print(f"{spec}: fwd[waves cap {cap}] {tf:7.1f} us ({fl / tf / 1e6:6.1f} TF)")
+    raw.vitmi_debug_attn_fwd_waves(0)
     for rnd in range(2):                     # interleaved rounds, one process (guide rule 24)
         for mode, name in ((0, "split"), (1, "fused")):
             raw.vitmi_debug_attn_bwd(mode)
             tb = timed(lambda: ops.attn_bwd(qkv, O, do, lse, dqkv, B, N, H, hd, scale, dbias_part=part))
             print(f"   bwd[{name}] {tb:7.1f} us ({2.5 * fl / tb / 1e6:6.1f} TF)")
+    raw.vitmi_debug_attn_bwd(1)
+    buf = torch.zeros(64 * 8, dtype=torch.int64, device="cuda")
+    raw.vitmi_debug_attn_stamps.argtypes = [ctypes.c_void_p]
+    raw.vitmi_debug_attn_stamps(buf.data_ptr())
+    ops.attn_bwd(qkv, O, do, lse, dqkv, B, N, H, hd, scale, dbias_part=part)
+    torch.cuda.synchronize()
+    raw.vitmi_debug_attn_stamps(None)
+    t = buf.cpu().view(64, 8)[:, :5]
+    d = (t[:, 1:] - t[:, :-1]).float()
+    print("   fused timeline, median cycles over 64 workgroups: stage %d, K frags + zero dQ %d, loop %d, stores + bias sums %d" %
+          tuple(d.median(0).values.tolist()))
     raw.vitmi_debug_attn_bwd(-1)

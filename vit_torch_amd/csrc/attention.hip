@@ -34,6 +34,12 @@ constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr int CHUNK_MAX = 128;     // rows of the streamed side resident in LDS
 
+__device__ __forceinline__ unsigned long long attn_stamp() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  return t;
+}
+
 __device__ __forceinline__ bf16x4 ds_read_tr16(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, p));
 }
@@ -551,9 +557,15 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16* __restr
                                                              const float* __restrict__ lse,
                                                              bf16* __restrict__ dqkv, int N, int H,
                                                              float scale, float scale_log2e,
-                                                             float* __restrict__ dbias_part) {
+                                                             float* __restrict__ dbias_part,
+                                                             unsigned long long* dbg) {
   using C = AttnCfg<HD>;
   using F = FusedBwdCfg<HD>;
+  // diagnostic timeline (armed by tools/attn_bench.py --stamps only): first 64 workgroups
+  const int dbg_slot = (int)blockIdx.x - 1536;     // mid-launch workgroups: steady state, not the cold start
+  const bool dbg_on = dbg != nullptr && dbg_slot >= 0 && dbg_slot < 64;
+  unsigned long long tl[5] = {0, 0, 0, 0, 0};
+  if (dbg_on) tl[0] = attn_stamp();
   constexpr int QS = F::QS, DQS = F::DQS, CPR = HD / 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
@@ -582,32 +594,45 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16* __restr
   for (int s = 0; s < C::KSTEPS; ++s)
     vf[s] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)krow * ts + 16 * s + 8 * h5);
 
-  // ---- stage Q, dO (and delta = rowsum(dO * O)), K; rows >= N are zero
-  for (int c = tid; c < NP * CPR; c += nthr) {
-    const int row = c / CPR, pc = c % CPR;
-    bf16x8 q8, d8, o8, k8;
+  // ---- stage Q, dO (and delta = rowsum(dO * O)), K; rows >= N are zero.  NP*CPR pieces of
+  // 16 B over nthr = NP*2 threads = CPR/2 pieces per thread and matrix: ALL the loads are
+  // issued before the first LDS store (one HBM round trip, not one per piece).
+  constexpr int IT = CPR / 2;
+  bf16x8 q8[IT], d8[IT], o8[IT], k8[IT];
+  float lv[IT];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { q8[e] = (bf16)0.f; d8[e] = (bf16)0.f; o8[e] = (bf16)0.f; k8[e] = (bf16)0.f; }
-    if (row < N) {
-      q8 = *reinterpret_cast<const bf16x8*>(qb + (int64_t)row * ts + pc * 8);
-      k8 = *reinterpret_cast<const bf16x8*>(kb_ + (int64_t)row * ts + pc * 8);
-      d8 = *reinterpret_cast<const bf16x8*>(dob + (int64_t)row * os + pc * 8);
-      o8 = *reinterpret_cast<const bf16x8*>(ob + (int64_t)row * os + pc * 8);
+  for (int i = 0; i < IT; ++i) {
+    // unconditional loads from a clamped row (a branch around a load makes hipcc wait for
+    // each one separately); rows >= N are zeroed by the selects below
+    const int c = tid + i * nthr, row = min(c / CPR, N - 1), pc = c % CPR;
+    q8[i] = *reinterpret_cast<const bf16x8*>(qb + (int64_t)row * ts + pc * 8);
+    k8[i] = *reinterpret_cast<const bf16x8*>(kb_ + (int64_t)row * ts + pc * 8);
+    d8[i] = *reinterpret_cast<const bf16x8*>(dob + (int64_t)row * os + pc * 8);
+    o8[i] = *reinterpret_cast<const bf16x8*>(ob + (int64_t)row * os + pc * 8);
+    lv[i] = lse[(int64_t)bh * N + row];           // with the batch: a load in the store loop would drain it each time
+  }
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int c = tid + i * nthr, row = c / CPR, pc = c % CPR;
+    if (row >= N) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { q8[i][e] = (bf16)0.f; d8[i][e] = (bf16)0.f; k8[i][e] = (bf16)0.f; }
     }
-    *reinterpret_cast<bf16x8*>(Ql + row * QS + pc * 16) = q8;
-    *reinterpret_cast<bf16x8*>(dOl + row * QS + pc * 16) = d8;
-    *reinterpret_cast<bf16x8*>(dQl + row * QS + pc * 16) = k8;
+    *reinterpret_cast<bf16x8*>(Ql + row * QS + pc * 16) = q8[i];
+    *reinterpret_cast<bf16x8*>(dOl + row * QS + pc * 16) = d8[i];
+    *reinterpret_cast<bf16x8*>(dQl + row * QS + pc * 16) = k8[i];
     float dot = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) dot = fmaf((float)d8[e], (float)o8[e], dot);
+    for (int e = 0; e < 8; ++e) dot = fmaf((float)d8[i][e], (float)o8[i][e], dot);
 #pragma unroll
     for (int off = 1; off < CPR; off <<= 1) dot += __shfl_xor(dot, off, 64);   // CPR consecutive lanes = one row
     if (pc == 0) {
       del_s[row] = dot;
-      lse_s[row] = row < N ? lse[(int64_t)bh * N + row] * LOG2E : INFINITY;    // +inf -> p = 0 for padded queries
+      lse_s[row] = row < N ? lv[i] * LOG2E : INFINITY;    // +inf -> p = 0 for padded queries
     }
   }
   __syncthreads();
+  if (dbg_on) tl[1] = attn_stamp();
   bf16x8 kf[C::KSTEPS];                            // B[k = d][n = key] of S = Q K^T
 #pragma unroll
   for (int s = 0; s < C::KSTEPS; ++s)
@@ -628,36 +653,62 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16* __restr
 #pragma unroll
   for (int db = 0; db < C::DB; ++db) { zero16(dk[db]); zero16(dv[db]); }
   const bool kvalid = key < N;
+  if (dbg_on) tl[2] = attn_stamp();
 
 #pragma unroll 1
   for (int t = 0; t < nw; ++t) {
     int j = w + t;
     if (j >= nw) j -= nw;
+    // Every LDS read of the step that does not depend on this step's dS is issued up
+    // front: the compiler cannot move a read of Ql / dOl / dQl above the T-tile stores
+    // (may alias), and would otherwise pay one LDS round trip per product.
+    bf16x8 aq[C::KSTEPS], ado[C::KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < C::KSTEPS; ++ks) {
+      aq[ks] = *reinterpret_cast<const bf16x8*>(Ql + (j * 32 + lr) * QS + (16 * ks + 8 * h5) * 2);
+      ado[ks] = *reinterpret_cast<const bf16x8*>(dOl + (j * 32 + lr) * QS + (16 * ks + 8 * h5) * 2);
+    }
+    f32x4 ls[4], de[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      ls[g] = *reinterpret_cast<const f32x4*>(lse_s + j * 32 + 8 * g + 4 * h5);
+      de[g] = *reinterpret_cast<const f32x4*>(del_s + j * 32 + 8 * g + 4 * h5);
+    }
+    bf16x8 doT[2][C::DB], qT[2][C::DB];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int db = 0; db < C::DB; ++db) {
+        doT[s2][db] = load_tr_frag(dOl, QS, j * 32 + 16 * s2, db * 32, lane);
+        qT[s2][db] = load_tr_frag(Ql, QS, j * 32 + 16 * s2, db * 32, lane);
+      }
+    char* dqrow = dQl + (j * 32 + lr) * DQS + 16 * h5;
+    f32x16 dq[C::DB];                              // accumulator rows d = db*32 + 8*g + 4*h5 + e
+#pragma unroll
+    for (int db = 0; db < C::DB; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(dqrow + (db * 32 + 8 * g) * 4);
+        dq[db][4 * g] = v[0]; dq[db][4 * g + 1] = v[1]; dq[db][4 * g + 2] = v[2]; dq[db][4 * g + 3] = v[3];
+      }
     f32x16 s, dp;
     zero16(s);
     zero16(dp);
 #pragma unroll
     for (int ks = 0; ks < C::KSTEPS; ++ks) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ql + (j * 32 + lr) * QS + (16 * ks + 8 * h5) * 2);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf[ks], s, 0, 0, 0);
-    }
-#pragma unroll
-    for (int ks = 0; ks < C::KSTEPS; ++ks) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(dOl + (j * 32 + lr) * QS + (16 * ks + 8 * h5) * 2);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, vf[ks], dp, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks], kf[ks], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ado[ks], vf[ks], dp, 0, 0, 0);
     }
     // rows = query inside the block (runs of 4: 8*g + 4*h5 + e), lane = key
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const f32x4 ls = *reinterpret_cast<const f32x4*>(lse_s + j * 32 + 8 * g + 4 * h5);
-      const f32x4 de = *reinterpret_cast<const f32x4*>(del_s + j * 32 + 8 * g + 4 * h5);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int r = 4 * g + e;
-        float p = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -ls[e]));
+        float p = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -ls[g][e]));
         p = kvalid ? p : 0.f;                      // zero-filled K rows give p = exp(-lse) != 0
         s[r] = p;
-        dp[r] = p * (dp[r] - de[e]);
+        dp[r] = p * (dp[r] - de[g][e]);
       }
     }
     // dS -> wave-private tile T[key][q] (bf16), 4 consecutive queries per store
@@ -668,65 +719,60 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16* __restr
       for (int e = 0; e < 4; ++e) o4[e] = (bf16)dp[4 * g + e];
       *reinterpret_cast<bf16x4*>(Tl + lr * 64 + (8 * g + 4 * h5) * 2) = o4;
     }
+    // dS^T back (same wave: DS operations execute in order); the dV / dK products cover
+    // the round trip
+    bf16x8 bT[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) bT[s2] = load_tr_frag(Tl, 64, 16 * s2, 0, lane);
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       const bf16x8 pf = pack8(s, 8 * s2);
       const bf16x8 dsf = pack8(dp, 8 * s2);
 #pragma unroll
       for (int db = 0; db < C::DB; ++db) {
-        const bf16x8 a = load_tr_frag(dOl, QS, j * 32 + 16 * s2, db * 32, lane);
-        dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf, dv[db], 0, 0, 0);
-        const bf16x8 a2 = load_tr_frag(Ql, QS, j * 32 + 16 * s2, db * 32, lane);
-        dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, dsf, dk[db], 0, 0, 0);
+        dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doT[s2][db], pf, dv[db], 0, 0, 0);
+        dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qT[s2][db], dsf, dk[db], 0, 0, 0);
       }
     }
-    // dQ^T(j)[d][q] += K^T[d][key] dS^T[key][q]; accumulator rows d = db*32 + 8*g + 4*h5 + e
-    {
-      char* dqrow = dQl + (j * 32 + lr) * DQS + 16 * h5;
-      f32x16 dq[C::DB];
+    // dQ^T(j)[d][q] += K^T[d][key] dS^T[key][q]
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
       for (int db = 0; db < C::DB; ++db)
+        dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT[s2][db], bT[s2], dq[db], 0, 0, 0);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(dqrow + (db * 32 + 8 * g) * 4);
-          dq[db][4 * g] = v[0]; dq[db][4 * g + 1] = v[1]; dq[db][4 * g + 2] = v[2]; dq[db][4 * g + 3] = v[3];
-        }
+    for (int db = 0; db < C::DB; ++db)
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 bT = load_tr_frag(Tl, 64, 16 * s2, 0, lane);
-#pragma unroll
-        for (int db = 0; db < C::DB; ++db)
-          dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT[s2][db], bT, dq[db], 0, 0, 0);
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = {dq[db][4 * g], dq[db][4 * g + 1], dq[db][4 * g + 2], dq[db][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(dqrow + (db * 32 + 8 * g) * 4) = v;
       }
-#pragma unroll
-      for (int db = 0; db < C::DB; ++db)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 v = {dq[db][4 * g], dq[db][4 * g + 1], dq[db][4 * g + 2], dq[db][4 * g + 3]};
-          *reinterpret_cast<f32x4*>(dqrow + (db * 32 + 8 * g) * 4) = v;
-        }
-    }
     __syncthreads();                               // the dQ blocks change hands
   }
 
-  if (kvalid) {
-    bf16* row = dqkv + (int64_t)(b * (int64_t)N + key) * ts + h * HD;
-    store_T_tile<HD>(row + H * HD, dk, scale, h5);
-    store_T_tile<HD>(row + 2 * H * HD, dv, 1.f, h5);
-  }
-  // dQ: fp32 LDS rows -> scaled bf16, 16-B pieces, coalesced
+  if (dbg_on) tl[3] = attn_stamp();
+  // dK, dV: transposed accumulators (lane = key, 4 consecutive d per register run) -> bf16
+  // rows in the dead Q / dO images, so that every global store below is a 16-B piece of a
+  // 128-B row segment (a lane-per-row store tail is issue-bound: guide, 'epilogue store tail')
+  store_T_tile<HD>(reinterpret_cast<bf16*>(Ql + key * QS), dk, scale, h5);
+  store_T_tile<HD>(reinterpret_cast<bf16*>(dOl + key * QS), dv, 1.f, h5);
+  __syncthreads();
   for (int c = tid; c < N * CPR; c += nthr) {
     const int row = c / CPR, pc = c % CPR;
+    bf16* grow = dqkv + (int64_t)(b * (int64_t)N + row) * ts + h * HD + pc * 8;
     const f32x4 a = *reinterpret_cast<const f32x4*>(dQl + row * DQS + pc * 32);
     const f32x4 b4 = *reinterpret_cast<const f32x4*>(dQl + row * DQS + pc * 32 + 16);
     bf16x8 o8;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { o8[e] = (bf16)(a[e] * scale); o8[4 + e] = (bf16)(b4[e] * scale); }
-    *reinterpret_cast<bf16x8*>(dqkv + (int64_t)(b * (int64_t)N + row) * ts + h * HD + pc * 8) = o8;
+    *reinterpret_cast<bf16x8*>(grow) = o8;
+    *reinterpret_cast<bf16x8*>(grow + H * HD) = *reinterpret_cast<const bf16x8*>(Ql + row * QS + pc * 16);
+    *reinterpret_cast<bf16x8*>(grow + 2 * H * HD) = *reinterpret_cast<const bf16x8*>(dOl + row * QS + pc * 16);
   }
   if constexpr (DBIAS) {
     // column sums of dQ / dK / dV of this (image, head): the qkv-bias gradient partials
-    float* red = reinterpret_cast<float*>(Ql);     // Q / dO are dead after the last barrier
+    __syncthreads();                               // the dK / dV rows have been read back
+    float* red = reinterpret_cast<float*>(Ql);
     colsum_T_tile<HD>(red + (w * 2 + 0) * HD, dk, scale, kvalid, lr, h5);
     colsum_T_tile<HD>(red + (w * 2 + 1) * HD, dv, 1.f, kvalid, lr, h5);
     float* redq = red + nw * 2 * HD;
@@ -749,6 +795,12 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16* __restr
       dbias_part[(int64_t)b * ts + which * H * HD + h * HD + d] = t;
     }
   }
+  if (dbg_on) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tl[4] = attn_stamp();
+    if (tid == 0)
+      for (int i = 0; i < 5; ++i) dbg[dbg_slot * 8 + i] = tl[i];
+  }
 }
 
 inline int attn_waves(int64_t N) {
@@ -770,6 +822,9 @@ static int check_attn(const void* qkv, int dtype, int64_t B, int64_t N, int64_t 
 int attn_fwd_f32(const float* qkv, float* out, float* lse, int64_t B, int64_t N, int64_t H, int64_t hd, float scale, hipStream_t stream);
 int attn_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int64_t B, int64_t N, int64_t H, int64_t hd, float scale, float* delta, hipStream_t stream);
 
+static int g_attn_fwd_waves = 0;     // diagnostic hook: waves (32 queries each) per forward workgroup, 0 = default
+extern "C" void vitmi_debug_attn_fwd_waves(int n) { g_attn_fwd_waves = n; }
+
 extern "C" int vitmi_attn_fwd(const void* qkv, void* out, float* lse, int dtype, int64_t B,
                               int64_t N, int64_t H, int64_t hd, float scale, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
@@ -778,7 +833,12 @@ extern "C" int vitmi_attn_fwd(const void* qkv, void* out, float* lse, int dtype,
   int rc = check_attn(qkv, dtype, B, N, H, hd, "attn_fwd");
   if (rc) return rc;
   VITMI_REQUIRE(is_aligned(out, 8), VITMI_E_ALIGN, "attn_fwd: out must be 8-B aligned");
-  const int nw = attn_waves(N);
+  // 4-wave workgroups (128 queries): three of them fit a CU (registers), so the K/V staging
+  // of one overlaps the softmax of the others; measured 9 % faster than one 7-wave
+  // workgroup per (image, head) at N = 197 although K/V are then staged twice
+  int nw = attn_waves(N);
+  const int cap = g_attn_fwd_waves > 0 ? g_attn_fwd_waves : 4;
+  if (cap < nw) nw = cap;
   dim3 grid((unsigned)((N + 32 * nw - 1) / (32 * nw)), (unsigned)(B * H));
   if (hd == 64) {
     const size_t lds = CHUNK_MAX * (AttnCfg<64>::KS + AttnCfg<64>::VS);
@@ -794,6 +854,8 @@ extern "C" size_t vitmi_attn_bwd_workspace(int64_t B, int64_t N, int64_t H) {
   return (size_t)(B * N * H) * sizeof(float);
 }
 
+static unsigned long long* g_attn_dbg = nullptr;
+extern "C" void vitmi_debug_attn_stamps(void* p) { g_attn_dbg = reinterpret_cast<unsigned long long*>(p); }
 static int g_attn_bwd_mode = -1;     // diagnostic / test hook: 0 = dkdv + dq kernels, 1 = fused where possible
 extern "C" void vitmi_debug_attn_bwd(int mode) { g_attn_bwd_mode = mode; }
 static bool attn_bwd_fused_ok(int64_t N, int64_t hd) {
@@ -838,7 +900,7 @@ extern "C" int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout
       }                                                                                                  \
       hipLaunchKernelGGL(kern, dim3((unsigned)(B * H)), dim3(64 * nw), lds, stream, (const bf16*)qkv,    \
                          (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, (int)N, (int)H, scale,   \
-                         scale * LOG2E, dbias_part);                                                     \
+                         scale * LOG2E, dbias_part, g_attn_dbg);                                         \
     } while (0)
     if (hd == 64) { if (dbias_part) LAUNCH_FUSED(64, true); else LAUNCH_FUSED(64, false); }
     else          { if (dbias_part) LAUNCH_FUSED(32, true); else LAUNCH_FUSED(32, false); }
