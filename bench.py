@@ -46,6 +46,35 @@ def parse():
     return ap.parse_args()
 
 
+def family(arch):
+    return "cait" if arch.startswith("cait") else "swin" if arch.startswith("swin") else "dino"
+
+
+def build_oracle(arch, img):
+    """CPU restatement of `arch` with the 10-class head of the workload."""
+    from oracle import vit_ref
+    fam = family(arch)
+    if fam == "dino":
+        return vit_ref.build(arch, classifier=10, img_size=img)
+    if fam == "cait":
+        from oracle import cait_ref
+        return cait_ref.build(arch, num_classes=10)
+    from oracle import swin_ref
+    return swin_ref.build(arch, num_classes=10, drop_path_rate=0.0)
+
+
+def build_model(arch, img, compute, residual):
+    from vit_torch_amd import VisionModelZoo
+    fam = family(arch)
+    kw = dict(compute_dtype=compute, residual_dtype=residual)
+    if fam == "dino":
+        return VisionModelZoo.get_model(arch, pretrained=False, classifier=10, img_size=img, **kw)
+    if fam == "cait":
+        return VisionModelZoo.get_model(arch, pretrained=False, classifier=10, **kw)
+    # DropPath at the configuration's rate, active as in the reference's training loop
+    return VisionModelZoo.get_model(arch, pretrained=False, classifier=10, **kw)
+
+
 def cpu_baseline(arch, img, batch, steps):
     """Oracle timed on the host cores (test infrastructure used as the CPU baseline)."""
     import torch.nn.functional as F
@@ -58,7 +87,7 @@ def cpu_baseline(arch, img, batch, steps):
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, 16))
     torch.set_num_threads(cores)
-    model = vit_ref.build(arch, classifier=10, img_size=img)
+    model = build_oracle(arch, img)
     vit_ref.seeded_init_(model, 1)
     opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9)
     g = torch.Generator("cpu").manual_seed(0)
@@ -94,12 +123,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    from vit_torch_amd import CrossEntropyLoss, FusedSGD, VisionModelZoo
+    from vit_torch_amd import CrossEntropyLoss, FusedSGD
     from vit_torch_amd.ddp import GradReducer
 
     torch.manual_seed(1)
-    model = VisionModelZoo.get_model(a.arch, pretrained=False, classifier=10, img_size=a.img,
-                                     compute_dtype=a.compute, residual_dtype=a.residual).to(dev)
+    model = build_model(a.arch, a.img, a.compute, a.residual).to(dev)
+    model.train()
     g = torch.Generator("cpu").manual_seed(1000 + rank)     # per-rank shard of the global batch
     x = torch.randn(a.batch, 3, a.img, a.img, generator=g).to(dev)
     y = torch.randint(0, 10, (a.batch,), generator=g).to(dev)
@@ -181,7 +210,8 @@ def main():
         ips = a.batch * world * a.steps / elapsed
         flop_img = GFLOP_PER_IMAGE if (a.arch == "dino_vitb16" and a.img == 224) else None
         out = {
-            "metric": "images/sec fwd+bwd ViT-B/16 224^2 bs=256/GPU",
+            "metric": ("images/sec fwd+bwd ViT-B/16 224^2 bs=256/GPU" if (a.arch == "dino_vitb16" and a.img == 224 and a.batch == 256)
+                       else f"images/sec fwd+bwd {a.arch} {a.img}^2 bs={a.batch}/GPU"),
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -41,7 +41,8 @@ def test_bad_arguments_are_rejected_without_a_gpu(lib):
     assert rc == -1
     assert b"M,N,K" in lib.vitmi_last_error_string()
     assert lib.vitmi_layernorm_fwd(None, 0, 0, None, None, None, 0, 0, None, None, 4, 8, 1e-6, None) == -1
-    assert lib.vitmi_layernorm_bwd_workspace(50432, 768) == 512 * 3 * 768 * 4
+    ws = lib.vitmi_layernorm_bwd_workspace(50432, 768)       # one partial row of 3*D floats per block
+    assert ws % (3 * 768 * 4) == 0 and 256 <= ws // (3 * 768 * 4) <= 2048
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

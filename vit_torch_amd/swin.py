@@ -28,7 +28,7 @@ import torch.nn as nn
 from . import ops
 from ._lib import EPI_BIAS_GELU, EPI_DGELU, EPI_RESIDUAL, GEMM_AUTO, VitmiError
 from .packing import ParamPack
-from .vit import Mlp, _DT, _EngineFn, _head_layers, _trunc_normal_
+from .vit import Mlp, _DT, _EngineFn, _head_layers, _trunc_normal_, engine_gemm
 
 
 def _relative_position_index(ws):
@@ -231,7 +231,7 @@ class SwinEngine:
         return self.pack.w(p)
 
     def _gemm(self, A, B, C, **k):
-        return ops.gemm(A, B, C, impl=self.gemm_impl, **k)
+        return engine_gemm(self, A, B, C, **k)
 
     def _ready(self, *objs):
         if self.reducer is None:

@@ -163,6 +163,22 @@ def _head_layers(head) -> Optional[List[tuple]]:
     return None
 
 
+def engine_gemm(eng, A, B, C, **k):
+    """ops.gemm with the engine's implementation switch; when eng.profile is a list, each
+    launch is bracketed by HIP events on the launch stream (bench.py's roofline leg)."""
+    if eng.profile is None:
+        return ops.gemm(A, B, C, impl=eng.gemm_impl, **k)
+    akm, bkm = k.get("a_kmajor", True), k.get("b_kmajor", True)
+    Kdim = A.shape[1] if akm else A.shape[0]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ops.gemm(A, B, C, impl=eng.gemm_impl, **k)
+    e1.record()
+    name = "gemm_" + ("n" if akm else "t") + ("t" if bkm else "n")
+    eng.profile.append((name, (C.shape[0], C.shape[1], Kdim), 2.0 * C.shape[0] * C.shape[1] * Kdim, e0, e1))
+    return C
+
+
 class VitEngine:
     """Executes VisionTransformer forward / backward as a fixed kernel sequence.
 
@@ -206,17 +222,7 @@ class VitEngine:
         return self.pack.w(p)
 
     def _gemm(self, A, B, C, **k):
-        if self.profile is None:
-            return ops.gemm(A, B, C, impl=self.gemm_impl, **k)
-        akm, bkm = k.get("a_kmajor", True), k.get("b_kmajor", True)
-        Kdim = A.shape[1] if akm else A.shape[0]
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        ops.gemm(A, B, C, impl=self.gemm_impl, **k)
-        e1.record()
-        name = "gemm_" + ("n" if akm else "t") + ("t" if bkm else "n")
-        self.profile.append((name, (C.shape[0], C.shape[1], Kdim), 2.0 * C.shape[0] * C.shape[1] * Kdim, e0, e1))
-        return C
+        return engine_gemm(self, A, B, C, **k)
 
     def _ready(self, *mods_or_params):
         if self.reducer is None:
