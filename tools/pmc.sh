@@ -1,0 +1,12 @@
+#!/bin/bash
+# usage (on the GPU box): tools/pmc.sh <tag> [bench args...]  -> gpurun_out/<tag>_pmc_traffic.json
+# two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) of the same bench command, no trace domains
+set -e
+tag=$1; shift
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${tag}_fetch -- python3 $R/bench.py --no-cpu-baseline "$@" > $R/gpurun_out/${tag}_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${tag}_write -- python3 $R/bench.py --no-cpu-baseline "$@" > $R/gpurun_out/${tag}_write.log 2>&1
+cd $R
+python3 tools/pmc_traffic.py gpurun_out/${tag}_fetch gpurun_out/${tag}_write gpurun_out/${tag}_pmc_traffic.json > gpurun_out/${tag}_pmc_traffic.txt
+rm -rf gpurun_out/${tag}_fetch gpurun_out/${tag}_write
