@@ -76,7 +76,12 @@ def test_hot_shapes_take_the_fast_gemm(lib):
     assert ops.gemm_uses_fast(M, D, 3 * D, b_kmajor=False)                           # qkv dgrad
     assert ops.gemm_uses_fast(3 * D, D, M, a_kmajor=False, b_kmajor=False, c_dtype=F32)   # qkv wgrad
     assert ops.gemm_uses_fast(D, 4 * D, M, a_kmajor=False, b_kmajor=False, c_dtype=F32)   # fc2 wgrad
-    # ragged shapes and fp32 operands go to the generic kernel
+    # fp32 operands, N % 8 != 0 and K % 32 != 0 go to the generic kernel
     assert not ops.gemm_uses_fast(256, 10, D, in_dtype=F32, c_dtype=F32)
-    assert not ops.gemm_uses_fast(640, 384, 384)          # M not a multiple of 256
+    assert not ops.gemm_uses_fast(640, 10, 384)
+    assert not ops.gemm_uses_fast(401408, 96, 48)         # Swin patch embed: K = 3*4*4
+    # ragged bf16 shapes take the 256x128-tile kernel (clamped loads, masked stores)
+    assert ops.gemm_uses_fast(640, 384, 384)              # M not a multiple of 256
+    assert ops.gemm_uses_fast(401408, 288, 96)            # Swin-T stage 0 qkv
+    assert ops.gemm_uses_fast(96, 96, 401408, a_kmajor=False, b_kmajor=False, c_dtype=F32)
     assert ops.gemm_uses_fast(256 * 5, 1152, 384)         # ViT-S qkv: N % 128 == 0 -> 256x128 tiles

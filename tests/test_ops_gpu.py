@@ -428,6 +428,65 @@ def test_gemm_fast_layouts(ops, pipe, layout, M, N, K, cdt):
     assert_close(f"gemm_fast[{layout}]", C, want, 1e-4 if cdt == torch.float32 else TOL[cdt])
 
 
+RAGGED = [(392, 96, 96), (6272, 288, 96), (1000, 200, 160), (264, 8, 64), (3136, 384, 96), (520, 1152, 384)]
+
+
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("M,N,K", RAGGED)
+def test_gemm_ragged_shapes_take_the_256x128_kernel(ops, layout, M, N, K):
+    """Swin's C = 96/192 stages and odd batch sizes: M, N not multiples of the tile, K % 32 == 0.
+    Surplus tile rows / columns are clamped duplicates whose stores are masked: the canary
+    border around C must stay untouched."""
+    from vit_torch_amd._lib import GEMM_FAST
+    if layout == "tn":
+        M, K = (M // 8 * 8), max(64, K // 32 * 32)
+    akm, bkm = {"nt": (True, True), "nn": (True, False), "tn": (False, False)}[layout]
+    assert ops.gemm_uses_fast(M, N, K, a_kmajor=akm, b_kmajor=bkm)
+    a, b = bf16_round(gen((M, K), 1)), bf16_round(gen((N, K), 2))
+    want = a @ b.t()
+    A = dev(a if akm else a.t().contiguous(), torch.bfloat16)
+    B = dev(b if bkm else b.t().contiguous(), torch.bfloat16)
+    for cdt in (torch.float32, torch.bfloat16):
+        buf = torch.full((M + 2, N + 16), 777.0, device="cuda").to(cdt)
+        C = buf[1:M + 1, 8:8 + N]
+        ops.gemm(A, B, C, a_kmajor=akm, b_kmajor=bkm, impl=GEMM_FAST)
+        assert_close(f"ragged[{layout}]", C, want, 1e-4 if cdt == torch.float32 else TOL[cdt])
+        border = buf.clone()
+        border[1:M + 1, 8:8 + N] = 777.0
+        assert (border == 777.0).all(), "store outside the M x N result"
+
+
+def test_gemm_ragged_epilogues(ops):
+    from vit_torch_amd._lib import EPI_BIAS_GELU, EPI_DGELU, EPI_RESIDUAL, GEMM_FAST
+    M, N, K = 1000, 96, 160
+    bt = torch.bfloat16
+    a, b = bf16_round(gen((M, K), 3)), bf16_round(gen((N, K), 4, 0.2))
+    bias = gen((N,), 5)
+    A, B, Bt, bias_d = dev(a, bt), dev(b, bt), dev(b.t().contiguous(), bt), dev(bias)
+    acc = a @ b.t()
+    H = torch.empty((M, N), device="cuda", dtype=bt)
+    P = torch.empty((M, N), device="cuda", dtype=bt)
+    ops.gemm(A, B, H, epilogue=EPI_BIAS_GELU, bias=bias_d, C2=P, impl=GEMM_FAST)
+    assert_close("pre", P, acc + bias, TOL[bt])
+    assert_close("gelu", H, F.gelu(bf16_round(acc + bias)), TOL[bt])
+    r, gam = gen((M, N), 7), gen((N,), 8)
+    rsc = torch.tensor([1.25, 0.0, 1.25, 0.0, 1.25])
+    X = torch.empty((M, N), device="cuda")
+    ops.gemm(A, B, X, epilogue=EPI_RESIDUAL, bias=bias_d, R=dev(r), gamma=dev(gam), rowscale=dev(rsc),
+             rows_per_group=200, impl=GEMM_FAST)
+    assert_close("residual", X, r + rsc.repeat_interleave(200)[:, None] * gam * (acc + bias), 1e-4)
+    aux = bf16_round(gen((M, N), 9))
+    Dg = torch.empty((M, N), device="cuda", dtype=bt)
+    ops.gemm(A, Bt, Dg, b_kmajor=False, epilogue=EPI_DGELU, aux=dev(aux, bt), impl=GEMM_FAST)
+    assert_close("dgelu", Dg, acc * gelu_grad(aux), TOL[bt])
+    # weight-gradient form with split-K: [N x K_out] = dy^T x over M tokens
+    W = torch.empty((N, K), device="cuda")
+    Mk = M // 32 * 32 - 32                           # 960 tokens: an odd number of 32-deep slabs per split
+    dy = bf16_round(gen((Mk, N), 10))
+    ops.gemm(dev(dy, bt), A[:Mk], W, a_kmajor=False, b_kmajor=False, impl=GEMM_FAST)
+    assert_close("wgrad", W, dy.t() @ a[:Mk], 1e-4)
+
+
 def test_gemm_fast_epilogues(ops, pipe):
     from vit_torch_amd._lib import (EPI_BIAS_GELU, EPI_DGELU, EPI_PATCH_POS, EPI_RESIDUAL, GEMM_FAST)
     M, N, K = 512, 256, 192

@@ -635,11 +635,12 @@ static int tile_mode() {
   }
   return mode;
 }
-// 256x128 tiles are used when forced, or when N is a multiple of 128 but not of 256
-// (D = 384 models); measured equal-or-slower than 256x256 on the ViT-B shapes
+// 256x128 tiles (ragged-shape capable) are used when forced, or whenever the shape is not
+// a whole number of 256x256x64 tiles (D = 96..384 models, odd batch sizes); measured
+// equal-or-slower than 256x256 on the ViT-B shapes
 static bool use_tile2(const GemmArgs& g) {
   if (!gemm_fast2_shape_ok(g)) return false;
-  return tile_mode() == 2 || (g.N % BN) != 0;
+  return tile_mode() == 2 || (g.M % BM) != 0 || (g.N % BN) != 0 || (g.K % BK) != 0;
 }
 
 // which (layout, epilogue, output dtype) combinations are instantiated

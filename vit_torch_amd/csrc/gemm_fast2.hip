@@ -21,7 +21,13 @@
 
 namespace {
 
-constexpr int BM2 = 256, BN2 = 128, BK2 = 64;    // K must be a multiple of 64 (2 slabs)
+constexpr int BM2 = 256, BN2 = 128, BK2 = 64;    // split-K plans count 64-deep steps; K % 32 == 0
+// Ragged shapes (M, N not multiples of the tile; Swin's C = 96 / 192 stages, odd batch
+// sizes): operand rows / column chunks beyond the matrix are CLAMPED to the last valid
+// one when the per-lane source offsets are built (once, outside the main loop), so the
+// LDS-DMA never leaves the buffers and the surplus rows/columns of the tile hold
+// duplicates; the epilogue masks their stores.  An output column depends only on its own
+// B column and an output row only on its own A row, so duplicates cannot leak.
 constexpr int A_SLAB = 256 * 32 * 2;             // 16 KiB
 constexpr int B_SLAB = 128 * 32 * 2;             //  8 KiB
 constexpr int STAGE2 = A_SLAB + B_SLAB;          // 24 KiB
@@ -35,16 +41,19 @@ template <bool KM, int ROWS> struct Plan2 {
   const char* base[NP];
   uint32_t off[NP];
   int64_t step;
-  __device__ __forceinline__ void init(const bf16* X, int64_t ld, int64_t r0, int64_t k0, int wave, int lane) {
+  // R = rows (k-major) / columns (k-minor) the matrix really has along the tile's dimension
+  __device__ __forceinline__ void init(const bf16* X, int64_t ld, int64_t r0, int64_t k0, int64_t R, int wave, int lane) {
     if constexpr (KM) {    // subtiles of 16 rows x 32 k (64-B rows), XOR byte bit5 ^= bit9
       const int pb = 16 * lane;
       const int lb = pb ^ (((pb >> 9) & 1) << 5);
       const int row = lb >> 6, ch = (lb & 63) >> 4;
+      const int last = (int)(R - 1 - r0);          // >= 0: the tile starts inside the matrix
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
         const int st = wave * NP + i;
-        base[i] = reinterpret_cast<const char*>(X + (r0 + st * 16) * ld + k0);
-        off[i] = (uint32_t)((row * ld + ch * 8) * 2);
+        const int rel = min(st * 16 + row, last);
+        base[i] = reinterpret_cast<const char*>(X + r0 * ld + k0);
+        off[i] = (uint32_t)((rel * ld + ch * 8) * 2);
       }
       step = 64;
     } else {               // 32 k-rows of ROWS*2 bytes; one piece = 1024/(ROWS*2) k-rows
@@ -58,8 +67,9 @@ template <bool KM, int ROWS> struct Plan2 {
         const int pc16 = lane % LPR;
         const int key = (row & 3) | (((row >> 3) & 1) << 2);
         const int c32 = (pc16 >> 1) ^ key;
+        const int col = min(c32 * 16 + (pc16 & 1) * 8, (int)(R - 8 - r0));   // R % 8 == 0
         base[i] = reinterpret_cast<const char*>(X + (k0 + pc * RPP) * ld + r0);
-        off[i] = (uint32_t)(((lane / LPR) * ld + c32 * 16 + (pc16 & 1) * 8) * 2);
+        off[i] = (uint32_t)(((lane / LPR) * ld + col) * 2);
       }
       step = 64 * ld;
     }
@@ -143,16 +153,17 @@ __global__ __launch_bounds__(NT2, 2) void gemm_fast2_kernel(GemmArgs g, int tile
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) { acc[ni][mi][0] = 0.f; acc[ni][mi][1] = 0.f; acc[ni][mi][2] = 0.f; acc[ni][mi][3] = 0.f; }
 
-  const int nt_all = (int)(g.K / BK2);
-  const int kt0 = SPLITK ? split * ksps : 0;
-  const int nt = SPLITK ? min(ksps, nt_all - kt0) : nt_all;
-  const int ns = 2 * nt;
-  const int64_t kb0 = (int64_t)kt0 * BK2;
+  // k range of this block in 32-deep slabs (ksps counts 64-deep steps)
+  const int ns_all = (int)(g.K / 32);
+  const int ks0 = SPLITK ? split * ksps * 2 : 0;
+  const int nsplit = SPLITK ? nwg / ntiles : 1;    // the last split also takes an odd final slab
+  const int ns = !SPLITK ? ns_all : (split == nsplit - 1 ? ns_all - ks0 : ksps * 2);
+  const int64_t kb0 = (int64_t)ks0 * 32;
 
   Plan2<A_KM, 256> pa;
   Plan2<B_KM, 128> pb_;
-  pa.init(A, g.lda, m0, kb0, wave, lane);
-  pb_.init(B, g.ldb, n0, kb0, wave, lane);
+  pa.init(A, g.lda, m0, kb0, g.M, wave, lane);
+  pb_.init(B, g.ldb, n0, kb0, g.N, wave, lane);
   uint32_t fa[8], fb[4];
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi) fa[mi] = frag_off2<A_KM, 256>(wm * 8 + mi, lane);
@@ -164,7 +175,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_fast2_kernel(GemmArgs g, int tile
     pb_.issue(st + A_SLAB, j, wave);
   };
   issue(0);
-  issue(1);                                        // ns >= 2 always
+  if (ns > 1) issue(1);
   int stage = 0;
 #pragma unroll 1
   for (int j = 0; j < ns; ++j) {
@@ -207,13 +218,14 @@ __global__ __launch_bounds__(NT2, 2) void gemm_fast2_kernel(GemmArgs g, int tile
   float bias_r[W], gamma_r[W];
 #pragma unroll
   for (int i = 0; i < W; ++i) { bias_r[i] = 0.f; gamma_r[i] = 1.f; }
+  const int64_t ncol = n0 + wn * 64 + rc;
+  const bool col_ok = ncol < g.N;                  // N % 8 == 0: a lane's W columns are all in or all out
   if constexpr (!SPLITK) {
-    if (g.e.bias) loadv<float, W>(g.e.bias + n0 + wn * 64 + rc, bias_r);
-    if (MODE == VITMI_EPI_RESIDUAL && g.e.gamma) loadv<float, W>(g.e.gamma + n0 + wn * 64 + rc, gamma_r);
+    if (g.e.bias && col_ok) loadv<float, W>(g.e.bias + ncol, bias_r);
+    if (MODE == VITMI_EPI_RESIDUAL && g.e.gamma && col_ok) loadv<float, W>(g.e.gamma + ncol, gamma_r);
   }
   constexpr int NJ = 16 / RPI;                     // row groups per strip
   const bool side = !SPLITK && epi_has_side<MODE, TC>(g.e);
-  const int64_t ncol = n0 + wn * 64 + rc;
   float sx[2][NJ][W];                              // side inputs: this strip and the next
 #pragma unroll
   for (int j = 0; j < NJ; ++j)
@@ -221,14 +233,19 @@ __global__ __launch_bounds__(NT2, 2) void gemm_fast2_kernel(GemmArgs g, int tile
     for (int i = 0; i < W; ++i) { sx[0][j][i] = 0.f; sx[1][j][i] = 0.f; }
   if (side) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) epi_side<MODE, TC, W>(g.e, m0 + wm * 128 + j * RPI + rr, ncol, sx[0][j]);
+    for (int j = 0; j < NJ; ++j) {
+      const int64_t ms = m0 + wm * 128 + j * RPI + rr;
+      if (col_ok && ms < g.M) epi_side<MODE, TC, W>(g.e, ms, ncol, sx[0][j]);
+    }
   }
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi) {
     if (side && mi + 1 < 8) {
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        epi_side<MODE, TC, W>(g.e, m0 + wm * 128 + (mi + 1) * 16 + j * RPI + rr, ncol, sx[(mi + 1) & 1][j]);
+      for (int j = 0; j < NJ; ++j) {
+        const int64_t ms = m0 + wm * 128 + (mi + 1) * 16 + j * RPI + rr;
+        if (col_ok && ms < g.M) epi_side<MODE, TC, W>(g.e, ms, ncol, sx[(mi + 1) & 1][j]);
+      }
     }
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
@@ -243,10 +260,12 @@ __global__ __launch_bounds__(NT2, 2) void gemm_fast2_kernel(GemmArgs g, int tile
         v[4 * qq] = t4[0]; v[4 * qq + 1] = t4[1]; v[4 * qq + 2] = t4[2]; v[4 * qq + 3] = t4[3];
       }
       const int64_t m = m0 + wm * 128 + mi * 16 + row;
-      if constexpr (SPLITK)
-        storev<float, W>(ws + ((int64_t)split * g.M + m) * g.N + ncol, v);
-      else
-        epi_row<MODE, TC, W>(g.e, m, ncol, v, bias_r, gamma_r, sx[mi & 1][j]);
+      if (col_ok && m < g.M) {                     // surplus rows / columns of a ragged tile
+        if constexpr (SPLITK)
+          storev<float, W>(ws + ((int64_t)split * g.M + m) * g.N + ncol, v);
+        else
+          epi_row<MODE, TC, W>(g.e, m, ncol, v, bias_r, gamma_r, sx[mi & 1][j]);
+      }
     }
   }
 }
@@ -283,7 +302,7 @@ inline void splitk_plan2(int tiles, int nt, int* splits, int* ksps) {
 
 template <bool A_KM, bool B_KM, int MODE, typename TC>
 int launch2(const GemmArgs& g, hipStream_t stream) {
-  const int tiles_m = (int)(g.M / BM2), tiles_n = (int)(g.N / BN2);
+  const int tiles_m = (int)((g.M + BM2 - 1) / BM2), tiles_n = (int)((g.N + BN2 - 1) / BN2);
   const int nwg = tiles_m * tiles_n;
   if constexpr (MODE == VITMI_EPI_STORE && sizeof(TC) == 4) {
     int splits, ksps;
@@ -319,12 +338,19 @@ int launch2(const GemmArgs& g, hipStream_t stream) {
 
 }  // namespace
 
-bool gemm_fast2_shape_ok(const GemmArgs& g) { return g.M % BM2 == 0 && g.N % BN2 == 0 && g.K % BK2 == 0; }
+// any M, N % 8 == 0 (a lane stores 4-8 consecutive columns), K a multiple of the 32-deep slab;
+// a k-minor A ([K][M], the weight-gradient form) is staged in 8-column chunks: M % 8 == 0
+bool gemm_fast2_shape_ok(const GemmArgs& g) {
+  if (g.N % 8 != 0 || g.K % 32 != 0 || g.K < 64 || g.N < 8) return false;
+  if (!g.a_km && (g.M % 8 != 0 || g.M < 8)) return false;
+  const int64_t tiles = ((g.M + BM2 - 1) / BM2) * ((g.N + BN2 - 1) / BN2);
+  return tiles < (1 << 30) && g.lda < (1 << 22) && g.ldb < (1 << 22);   // 32-bit per-lane offsets
+}
 
 size_t gemm_fast2_workspace(const GemmArgs& g) {
   if (g.e.mode != VITMI_EPI_STORE || g.e.c_bf16) return 0;
   int splits, ksps;
-  splitk_plan2((int)(g.M / BM2 * (g.N / BN2)), (int)(g.K / BK2), &splits, &ksps);
+  splitk_plan2((int)(((g.M + BM2 - 1) / BM2) * ((g.N + BN2 - 1) / BN2)), (int)(g.K / BK2), &splits, &ksps);
   return splits > 1 ? (size_t)splits * g.M * g.N * sizeof(float) : 0;
 }
 
