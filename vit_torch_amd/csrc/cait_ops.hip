@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const T* __restrict
 
 inline int th_bwd_blocks(int64_t rows) {
   int64_t b = (rows + 3) / 4;
-  return (int)(b < 1024 ? b : 1024);
+  return (int)(b < 512 ? b : 512);      // one partial row per wave: keep the fold short
 }
 
 // ---- class attention: one wave per (b, h); q [B, H*hd] (already scaled by the caller via
@@ -368,10 +368,9 @@ extern "C" int vitmi_th_softmax_bwd(const void* S, const void* P, const void* dP
   if (rc) return rc;
   const int64_t stride = 2 * H * H + 2 * H;
   const int nrows = nblk * 4;
-  if ((rc = vitmi_reduce_rows(part, nrows, H * H, stride, dWl, stream))) return rc;
-  if ((rc = vitmi_reduce_rows(part + H * H, nrows, H, stride, dbl, stream))) return rc;
-  if ((rc = vitmi_reduce_rows(part + H * H + H, nrows, H * H, stride, dWw, stream))) return rc;
-  return vitmi_reduce_rows(part + 2 * H * H + H, nrows, H, stride, dbw, stream);
+  float* const outs[4] = {dWl, dbl, dWw, dbw};
+  const int widths[4] = {(int)(H * H), (int)H, (int)(H * H), (int)H};
+  return vitmi_reduce_rows_segs(part, nrows, stride, outs, widths, stream);
 }
 
 extern "C" int vitmi_class_attn_fwd(const void* q, const void* k, const void* v, int64_t kv_token_stride,

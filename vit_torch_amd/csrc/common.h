@@ -21,6 +21,8 @@ int vitmi_fail(int code, const char* fmt, ...);
 int vitmi_check_launch(const char* what);
 // out[c] = sum_{r<S} part[r*ld + c], c < N (elementwise.hip)
 int vitmi_reduce_rows(const float* part, int S, int64_t N, int64_t ld, float* out, hipStream_t stream);
+int vitmi_reduce_rows_segs(const float* part, int S, int64_t ld, float* const out[4], const int width[4],
+                           hipStream_t stream);   // four consecutive column segments, four destinations
 int vitmi_reduce_rows3(const float* part, int S, int64_t N, int64_t ld, float* out0, float* out1, float* out2,
                        hipStream_t stream);   // out2 may be null
 

@@ -154,6 +154,29 @@ __global__ __launch_bounds__(1024) void reduce_rows3_kernel(const float* __restr
   }
 }
 
+// one partial buffer whose row is up to four consecutive segments of different widths, each
+// with its own destination (talking-heads backward: dWl | dbl | dWw | dbw), in one launch
+struct RowSegs { float* out[4]; int end[4]; };
+__global__ __launch_bounds__(1024) void reduce_rows_segs_kernel(const float* __restrict__ part, int S,
+                                                                int64_t ld, RowSegs sg) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int n = sg.end[3];
+  float s = 0.f;
+  if (c < n)
+    for (int r = w; r < S; r += 16) s += part[(int64_t)r * ld + c];
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && c < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][lane];
+    const int k = c < sg.end[0] ? 0 : (c < sg.end[1] ? 1 : (c < sg.end[2] ? 2 : 3));
+    sg.out[k][c - (k == 0 ? 0 : sg.end[k - 1])] = t;
+  }
+}
+
 inline int colsum_splits(int64_t M) {
   int64_t s = (M + 3) / 4;
   return (int)(s < 128 ? s : 128);
@@ -257,6 +280,15 @@ int vitmi_reduce_rows3(const float* part, int S, int64_t N, int64_t ld, float* o
   hipLaunchKernelGGL(reduce_rows3_kernel, dim3((unsigned)((N + 63) / 64), segs), dim3(1024), 0, stream, part, S,
                      N, ld, out0, out1, out2);
   return vitmi_check_launch("reduce_rows3_kernel");
+}
+
+int vitmi_reduce_rows_segs(const float* part, int S, int64_t ld, float* const out[4], const int width[4],
+                           hipStream_t stream) {
+  RowSegs sg;
+  int e = 0;
+  for (int i = 0; i < 4; ++i) { sg.out[i] = out[i]; e += width[i]; sg.end[i] = e; }
+  hipLaunchKernelGGL(reduce_rows_segs_kernel, dim3((unsigned)((e + 63) / 64)), dim3(1024), 0, stream, part, S, ld, sg);
+  return vitmi_check_launch("reduce_rows_segs_kernel");
 }
 
 int vitmi_reduce_rows(const float* part, int S, int64_t N, int64_t ld, float* out, hipStream_t stream) {
