@@ -22,9 +22,12 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, pack, group=None, min_bucket_elems: int = 4 << 20):
+    def __init__(self, pack, group=None, min_bucket_elems: int = 4 << 20, force: bool = False):
+        """force: exchange even in a world of one (exercises the RCCL stream ordering on a
+        single GPU; tests only)."""
         self.pack = pack
         self.group = group
+        self.force = bool(force)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.min_bucket = int(min_bucket_elems)
         self._pending_lo: Optional[int] = None
@@ -34,7 +37,7 @@ class GradReducer:
 
     # called by the engine when the gradients of `params` are final
     def section_ready(self, params) -> None:
-        if self.world == 1 or not params:
+        if (self.world == 1 and not self.force) or not params:
             return
         lo, hi = self.pack.span(params)
         if self._pending_lo is None:
