@@ -220,8 +220,7 @@ class CaitEngine:
         hd = D // H
         Kp = Cin * p * p
         NS = _ru8(Np)
-        if pk.shadow is not None:
-            ops.cast(pk.flat, pk.shadow)
+        pk.refresh_shadow()
         f32 = torch.float32
 
         def new(r, c, dt):

@@ -42,4 +42,6 @@ class FusedSGD(torch.optim.Optimizer):
                     self._mom[id(pack)] = buf
                 ops.sgd_momentum(pack.flat, pack.grad, buf, pack.shadow, group["lr"],
                                  group["momentum"], group["grad_scale"])
+                if pack.shadow is not None:
+                    pack.mark_shadow_current()     # the kernel wrote master and shadow together
         return loss

@@ -57,6 +57,23 @@ class ParamPack:
     def g(self, p) -> torch.Tensor:
         return self._slice(self.grad, p)
 
+    # ---- bf16 shadow freshness: torch bumps the flat buffer's version counter on every
+    # in-place write through it or any view (optimizer updates, load_state_dict, init);
+    # our own kernels write through raw pointers and report what they refreshed
+    def refresh_shadow(self) -> None:
+        """Cast fp32 -> bf16 unless the shadow already mirrors the current master values."""
+        if self.shadow is None:
+            return
+        v = self.flat._version
+        if getattr(self, "_shadow_version", None) != v:
+            from . import ops
+            ops.cast(self.flat, self.shadow)
+            self._shadow_version = v
+
+    def mark_shadow_current(self) -> None:
+        """Called by a kernel that rewrote master AND shadow together (FusedSGD)."""
+        self._shadow_version = self.flat._version
+
     def w(self, p) -> torch.Tensor:
         """GEMM-operand view: bf16 shadow when there is one, else the fp32 master."""
         return self._slice(self.shadow if self.shadow is not None else self.flat, p)

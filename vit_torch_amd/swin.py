@@ -252,8 +252,7 @@ class SwinEngine:
         assert Hi == pe.img_size[0] and Wi == pe.img_size[1], \
             f"Input image size ({Hi}*{Wi}) doesn't match model ({pe.img_size[0]}*{pe.img_size[1]})."
         p = pe.patch_size[0]
-        if pk.shadow is not None:
-            ops.cast(pk.flat, pk.shadow)
+        pk.refresh_shadow()
 
         def new(r, c, dt):
             return torch.empty((r, c), dtype=dt, device=dev)

@@ -269,8 +269,7 @@ class VitEngine:
         H = m.blocks[0].attn.num_heads
         hd = D // H
         Kp = Cin * p * p
-        if self.pack.shadow is not None:
-            ops.cast(self.pack.flat, self.pack.shadow)
+        self.pack.refresh_shadow()
 
         def new(rows, cols, dt):
             return torch.empty((rows, cols), dtype=dt, device=dev)
