@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--residual", default="fp32", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the step from a captured HIP graph (single GPU; auto = try, fall back to eager)")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=2)
     return ap.parse_args()
@@ -140,12 +142,36 @@ def main():
         eng.reducer = reducer
     opt = FusedSGD(model.parameters(), lr=1e-3, momentum=0.9, grad_scale=1.0 / world)
 
-    def step():
+    def eager_step():
         opt.zero_grad()
         loss = crit(model(x), y)
         loss.backward()
         opt.step()
         return loss
+
+    def quick_ms(fn, n=3):
+        fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n * 1e3
+
+    step, graphed = eager_step, False
+    if world == 1 and a.graph != "off":
+        try:
+            from vit_torch_amd.graph import GraphedStep
+            gs = GraphedStep(model, crit, opt, x, y)
+            graph_step = lambda: gs(x, y)
+            # a graph pays off when the launch path, not the GPU, paces the step (small
+            # models / images); the big configurations run the same either way: keep the faster
+            if a.graph == "on" or quick_ms(graph_step) < 0.98 * quick_ms(eager_step):
+                step, graphed = graph_step, True
+        except Exception as e:          # capture is an optimisation: report and run eagerly
+            if a.graph == "on":
+                raise
+            print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); eager step", file=sys.stderr)
 
     def fence():
         if world > 1:
@@ -170,7 +196,7 @@ def main():
     roof = None
     if rank == 0:
         eng.profile = []
-        step()
+        eager_step()
         torch.cuda.synchronize()
         rows = {}
         for name, shape, flops, e0, e1 in eng.profile:
@@ -219,7 +245,7 @@ def main():
             "config": {"workload": f"{a.arch} {a.img}x{a.img} fwd+CE+bwd+SGD(momentum) step, "
                                    f"batch {a.batch}/GPU, 10 classes, random-init weights",
                        "global_batch": a.batch * world, "residual_stream": a.residual,
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}", "hip_graph": graphed},
             "loss": round(loss_value, 5),
             "step_mfma_frac": (round(ips / world * flop_img * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4)
                                if flop_img else None),

@@ -1,0 +1,60 @@
+"""GraphedStep: the captured HIP graph of a whole training step reproduces the eager steps."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _make():
+    from vit_torch_amd import CrossEntropyLoss, FusedSGD, VisionTransformer
+    torch.manual_seed(5)
+    m = VisionTransformer(img_size=32, patch_size=8, embed_dim=128, depth=3, num_heads=4, num_classes=10,
+                          compute_dtype="bf16").cuda()
+    m.head = torch.nn.Linear(128, 10, bias=False).cuda()
+    return m, CrossEntropyLoss(), FusedSGD(m.parameters(), lr=5e-2, momentum=0.9)
+
+
+def _batches(n):
+    g = torch.Generator("cpu").manual_seed(1)
+    return [(torch.randn(64, 3, 32, 32, generator=g).cuda(), torch.randint(0, 10, (64,), generator=g).cuda())
+            for _ in range(n)]
+
+
+def test_graph_replay_matches_eager_steps(lib):
+    from vit_torch_amd.graph import GraphedStep
+    data = _batches(5)
+    m, crit, opt = _make()
+    eager = []
+    for x, y in data:
+        opt.zero_grad()
+        loss = crit(m(x), y)
+        loss.backward()
+        opt.step()
+        eager.append(loss.item())
+    p_eager = m.engine().pack.flat.clone()
+
+    m2, crit2, opt2 = _make()
+    m2.load_state_dict({k: v for k, v in _make()[0].state_dict().items()})      # same seed -> same init
+    start = m2.engine().pack.flat.clone()
+    step = GraphedStep(m2, crit2, opt2, *data[0], warmup=1)
+    # the capture ran warm-up + capture passes on the first batch: restart from the initial state
+    with torch.no_grad():
+        m2.engine().pack.flat.copy_(start)
+    for st in opt2._mom.values():
+        st.zero_()
+    graphed = [step(x, y).item() for x, y in data]
+    assert graphed == pytest.approx(eager, rel=1e-5, abs=1e-6), (graphed, eager)
+    torch.testing.assert_close(m2.engine().pack.flat, p_eager, rtol=1e-5, atol=1e-6)
+
+
+def test_graph_recaptures_when_the_learning_rate_changes(lib):
+    from vit_torch_amd.graph import GraphedStep
+    (x, y), = _batches(1)
+    m, crit, opt = _make()
+    step = GraphedStep(m, crit, opt, x, y, warmup=1)
+    g0 = step.graph
+    step(x, y)
+    assert step.graph is g0
+    opt.param_groups[0]["lr"] = 1e-3
+    step(x, y)
+    assert step.graph is not g0, "a new LR must not be replayed with the old kernel argument"

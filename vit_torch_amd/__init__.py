@@ -6,5 +6,6 @@ from .vision_all import VisionModelZoo  # noqa: F401
 from .vit import VisionTransformer  # noqa: F401
 from .cait import cait_models  # noqa: F401
 from .swin import SwinTransformer  # noqa: F401
+from .graph import GraphedStep  # noqa: F401
 
-__all__ = ["VisionModelZoo", "VisionTransformer", "CrossEntropyLoss", "FusedSGD", "VitmiError"]
+__all__ = ["VisionModelZoo", "VisionTransformer", "CrossEntropyLoss", "FusedSGD", "GraphedStep", "VitmiError"]

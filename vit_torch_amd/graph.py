@@ -1,0 +1,81 @@
+"""Whole-step HIP graph: forward + loss + backward + optimizer captured once, replayed per batch.
+
+A training step of these models is 300-1500 kernel launches issued from Python; for the
+small configurations (dino_vits16 at 32x32: ~10 us of GPU work per launch) the launch path,
+not the GPU, paces the step.  Capturing the step in a hipGraph (through torch.cuda.graphs,
+which records everything launched on the capturing stream, our ctypes launches included)
+removes it.  Static shapes only: the graph owns input buffers that each call copies into.
+
+    step = GraphedStep(model, criterion, optimizer, x0, y0)
+    for x, y in loader:
+        loss = step(x, y)           # device tensor, valid until the next call
+
+Limits (checked or documented): parameters must only be changed by the captured optimizer
+between replays (re-capture after load_state_dict or a learning-rate change: the LR is a
+kernel argument baked into the graph; `step.recapture()`), single process (the RCCL
+exchange is not captured: use the eager step with GradReducer for data parallelism).
+"""
+from __future__ import annotations
+
+import torch
+
+from ._lib import VitmiError
+
+
+class GraphedStep:
+    def __init__(self, model, criterion, optimizer, x_example, y_example, warmup: int = 2):
+        if not x_example.is_cuda:
+            raise VitmiError("GraphedStep needs example inputs on the GPU")
+        eng = model.engine() if hasattr(model, "engine") else None
+        if eng is not None and getattr(eng, "reducer", None) is not None:
+            raise VitmiError("GraphedStep does not capture the RCCL gradient exchange; use the eager step")
+        self.model, self.criterion, self.optimizer = model, criterion, optimizer
+        self.x = x_example.detach().clone()
+        self.y = y_example.detach().clone()
+        self.warmup = int(warmup)
+        self.graph = None
+        self.loss = None
+        self.out = None
+        self._lrs = None
+        self.recapture()
+
+    def _eager(self):
+        self.optimizer.zero_grad(set_to_none=True)
+        out = self.model(self.x)
+        loss = self.criterion(out, self.y)
+        loss.backward()
+        self.optimizer.step()
+        return out, loss
+
+    def recapture(self):
+        """(Re)build the graph from the current parameters and optimizer settings."""
+        self.graph = None
+        # the warm-up passes run on a side stream (torch's capture recipe), so AccumulateGrad
+        # nodes of earlier eager steps live on another stream: expected here, not a hazard
+        quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if quiet is not None:
+            quiet(False)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                 # warm-up off the default stream: lazy
+            for _ in range(self.warmup):              # initialisation (LDS attributes, side
+                self._eager()                         # streams, workspaces) happens eagerly
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        self.optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(g):
+            out = self.model(self.x)
+            loss = self.criterion(out, self.y)
+            loss.backward()
+            self.optimizer.step()
+        self.graph, self.out, self.loss = g, out, loss
+        self._lrs = [grp["lr"] for grp in self.optimizer.param_groups]
+
+    def __call__(self, x, y):
+        if [grp["lr"] for grp in self.optimizer.param_groups] != self._lrs:
+            self.recapture()                          # the learning rate is baked into the graph
+        self.x.copy_(x, non_blocking=True)
+        self.y.copy_(y, non_blocking=True)
+        self.graph.replay()
+        return self.loss

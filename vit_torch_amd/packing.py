@@ -65,7 +65,9 @@ class ParamPack:
         if self.shadow is None:
             return
         v = self.flat._version
-        if getattr(self, "_shadow_version", None) != v:
+        # inside a graph capture the cast is always recorded: a replay then re-derives the
+        # shadow from whatever the master holds (weights loaded between replays stay correct)
+        if getattr(self, "_shadow_version", None) != v or torch.cuda.is_current_stream_capturing():
             from . import ops
             ops.cast(self.flat, self.shadow)
             self._shadow_version = v
