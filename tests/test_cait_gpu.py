@@ -112,6 +112,56 @@ def test_batched_gemm_on_qkv_views(ops, dt):
     assert_close("PV", O, Oref, tol)
 
 
+@pytest.mark.parametrize("B,N,H,hd", [(2, 196, 2, 48), (3, 37, 3, 48), (1, 197, 1, 64), (2, 50, 2, 32), (1, 256, 1, 48)])
+def test_small_batched_gemm_all_six_products(ops, B, N, H, hd):
+    """The one-workgroup-per-(image, head) kernel on the six products of talking-heads
+    attention and its backward, against fp32 einsum and bit-compared pad columns: the scores'
+    pad columns (N..NS) hold NaN on input and must neither be read into a result nor written."""
+    from vit_torch_amd._lib import GEMM_GENERIC
+    bt = torch.bfloat16
+    NS = (N + 7) // 8 * 8
+    D, D3 = H * hd, 3 * H * hd
+    qkv = bf16_round(gen((B, N, D3), 1))
+    do = bf16_round(gen((B, N, D), 2))
+    q, k, v = qkv.view(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)          # [B,H,N,hd]
+    dO = do.view(B, N, H, hd).permute(0, 2, 1, 3)
+    Pm = bf16_round(gen((B, H, N, N), 3).softmax(-1))
+    Q, DO = qkv.cuda().to(bt), do.cuda().to(bt)
+    Pd = torch.full((B, H, N, NS), float("nan"), device="cuda", dtype=bt)
+    Pd[..., :N] = Pm.cuda().to(bt)
+    kw = dict(batch=B * H, batch_inner=H)
+    sc = dict(c_bs=(H * N * NS, N * NS), ldc=NS)
+
+    def scores(X, ldx, xbs, boff, alpha, impl):
+        S = torch.full((B, H, N, NS), 777.0, device="cuda", dtype=bt)
+        ops.gemm_batched(X, Q, S, M=N, N=N, K=hd, lda=ldx, ldb=D3, a_kmajor=True, b_kmajor=True, a_bs=xbs,
+                         b_bs=(N * D3, hd), b_off=boff, alpha=alpha, impl=impl, **kw, **sc)
+        return S
+
+    for name, got, want in (
+            ("q k^T", scores(Q, D3, (N * D3, hd), D, 0.25, 0), (q @ k.transpose(-2, -1)) * 0.25),
+            ("dO v^T", scores(DO, D, (N * D, hd), 2 * D, 1.0, 0), dO @ v.transpose(-2, -1))):
+        assert_close(name, got[..., :N], want, 1.5e-2)
+        assert (got[..., N:] == 777.0).all(), "pad columns of the scores were written"
+
+    def apply(a_km, Y, ldy, ybs, yoff, Cbuf, ldc, cbs, coff, alpha):
+        ops.gemm_batched(Pd, Y, Cbuf, M=N, N=hd, K=N, lda=NS, ldb=ldy, ldc=ldc, a_kmajor=a_km, b_kmajor=False,
+                         a_bs=(H * N * NS, N * NS), b_bs=ybs, b_off=yoff, c_bs=cbs, c_off=coff, alpha=alpha, **kw)
+
+    O = torch.zeros((B, N, D), device="cuda", dtype=bt)
+    apply(True, Q, D3, (N * D3, hd), 2 * D, O, D, (N * D, hd), 0, 1.0)                       # O = P' v
+    assert_close("P v", O, (Pm @ v).transpose(1, 2).reshape(B, N, D), 1.5e-2)
+    dqkv = torch.zeros((B, N, D3), device="cuda", dtype=bt)
+    apply(False, DO, D, (N * D, hd), 0, dqkv, D3, (N * D3, hd), 2 * D, 1.0)                  # dV = P'^T dO
+    apply(True, Q, D3, (N * D3, hd), D, dqkv, D3, (N * D3, hd), 0, 0.5)                      # dQ = a dS k
+    apply(False, Q, D3, (N * D3, hd), 0, dqkv, D3, (N * D3, hd), D, 0.5)                     # dK = a dS^T q
+    got = dqkv.float().cpu().view(B, N, 3, H, hd)
+    assert_close("P^T dO", got[:, :, 2], (Pm.transpose(-2, -1) @ dO).permute(0, 2, 1, 3), 1.5e-2)
+    assert_close("dS k", got[:, :, 0], 0.5 * (Pm @ k).permute(0, 2, 1, 3), 1.5e-2)
+    assert_close("dS^T q", got[:, :, 1], 0.5 * (Pm.transpose(-2, -1) @ q).permute(0, 2, 1, 3), 1.5e-2)
+    assert torch.isfinite(dqkv.float()).all()
+
+
 def test_colsum_mul_and_scale_cast(ops):
     M, N = 333, 96
     x, y, sc = gen((M, N), 1), bf16_round(gen((M, N), 2)), gen((N,), 3)

@@ -25,6 +25,7 @@ SOURCES = [
     "gemm.hip",
     "gemm_fast.hip",
     "gemm_fast2.hip",
+    "gemm_small.hip",
     "layernorm.hip",
     "elementwise.hip",
     "attention.hip",

@@ -212,6 +212,17 @@ static int build_args(const vitmi_gemm_desc* d, GemmArgs* out) {
   return 0;
 }
 
+int gemm_small_form(const GemmArgs& g, int in_bf16);
+int gemm_small_launch(const GemmArgs& g, int form, hipStream_t stream);
+static int g_small_override = -1;    // diagnostic / test hook: 0 = never, 1 = also when impl == GENERIC, -1 = default
+extern "C" void vitmi_debug_gemm_small(int mode) { g_small_override = mode; }
+static bool small_lds_ok(const GemmArgs& g, int form) {
+  if (form == 0) return true;
+  const int64_t Kp = (g.K + 31) / 32 * 32, Mp = (g.M + 15) / 16 * 16;
+  const int64_t ry = g.N * 2 + (((g.N * 2) % 128 == 0) ? 32 : 0), rs = Mp * 2 + (((Mp * 2) % 128 == 0) ? 32 : 0);
+  return Kp * ry + (form == 2 ? 64 * rs : 0) <= 96 * 1024;
+}
+
 extern "C" int vitmi_gemm_uses_fast(const vitmi_gemm_desc* d) {
   GemmArgs g;
   if (build_args(d, &g) != 0) return 0;
@@ -240,6 +251,10 @@ extern "C" int vitmi_gemm(const vitmi_gemm_desc* d, void* stream_) {
   VITMI_REQUIRE(!d->colsum_part, VITMI_E_BADARG,
                 "gemm: colsum_part is produced only by the aligned bf16 path with EPI_DGELU (ask vitmi_gemm_uses_fast)");
 
+  if (d->impl != VITMI_GEMM_GENERIC || g_small_override == 1) {     // batched form: one workgroup per small problem
+    const int form = g_small_override == 0 ? -1 : gemm_small_form(g, in_bf16 ? 1 : 0);
+    if (form >= 0 && small_lds_ok(g, form)) return gemm_small_launch(g, form, stream);
+  }
   dim3 grid((unsigned)((g.N + GBN - 1) / GBN), (unsigned)((g.M + GBM - 1) / GBM), (unsigned)g.batch);
   VITMI_REQUIRE(grid.y <= 65535u, VITMI_E_SHAPE, "gemm: M too large for the generic kernel grid");
   if (in_bf16) hipLaunchKernelGGL(gemm_generic_kernel<bf16>, grid, dim3(256), 0, stream, g);

@@ -110,9 +110,10 @@ def gemm(A, B, C_out, *, a_kmajor=True, b_kmajor=True, epilogue=EPI_STORE, bias=
 
 
 def gemm_batched(A, B, C_out, *, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, batch, batch_inner,
-                 a_bs, b_bs, c_bs, a_off=0, b_off=0, c_off=0, alpha=1.0):
+                 a_bs, b_bs, c_bs, a_off=0, b_off=0, c_off=0, alpha=1.0, impl=GEMM_AUTO):
     """batch independent products on strided views of A/B/C storage (element offsets/strides):
-    C_z = alpha * op(A_z) op(B_z)^T, z = zo*batch_inner + zi.  Generic MFMA kernel."""
+    C_z = alpha * op(A_z) op(B_z)^T, z = zo*batch_inner + zi.  One workgroup per problem for
+    small bf16 problems (gemm_small.hip), else the generic MFMA kernel (impl=GEMM_GENERIC forces it)."""
     _need_cuda(A, B, C_out)
     assert A.dtype == B.dtype
     d = GemmDesc()
@@ -123,7 +124,7 @@ def gemm_batched(A, B, C_out, *, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, bat
     d.epilogue = EPI_STORE
     d.C, d.ldc, d.c_dtype = C_out.data_ptr() + c_off * C_out.element_size(), ldc, dtype_code(C_out)
     d.alpha = float(alpha)
-    d.impl = GEMM_GENERIC
+    d.impl = impl
     d.batch, d.batch_inner = batch, batch_inner
     d.a_bs[0], d.a_bs[1] = a_bs
     d.b_bs[0], d.b_bs[1] = b_bs
