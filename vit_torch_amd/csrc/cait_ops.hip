@@ -94,69 +94,80 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const T* __restrict
 #pragma unroll
     for (int c = 0; c < TH_MAXH; ++c) { aWl[a][c] = 0.f; aWw[a][c] = 0.f; }
   }
+  // Two passes per row, one 64-key chunk at a time (the whole row of S, P, dP' for 8 heads
+  // is 96 values per lane: holding it beside the 144 gradient accumulators leaves one wave
+  // per SIMD).  Pass 1: dP = Ww^T dP', the softmax row dots, dWw / dbw.  Pass 2 re-reads P
+  // (L2) and S: dS' = P (dP - dot), dS = Wl^T dS', dWl / dbl.  dP of all chunks stays in
+  // registers between the passes.
   for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < rows; row += (int64_t)gridDim.x * 4) {
     const int64_t b = row / N, i = row % N;
-    float s[TH_MAXH][TH_MAXC], p[TH_MAXH][TH_MAXC], g[TH_MAXH][TH_MAXC];
+    float dp[TH_MAXH][TH_MAXC], dot[TH_MAXH];
 #pragma unroll
-    for (int h = 0; h < TH_MAXH; ++h)
+    for (int hp = 0; hp < TH_MAXH; ++hp) dot[hp] = 0.f;
 #pragma unroll
-      for (int c = 0; c < TH_MAXC; ++c) {
-        const int j = c * 64 + lane;
+    for (int c = 0; c < TH_MAXC; ++c) {
+      const int j = c * 64 + lane;
+      if (c * 64 >= Nk) {                          // wave-uniform: chunk beyond the row
+#pragma unroll
+        for (int hp = 0; hp < TH_MAXH; ++hp) dp[hp][c] = 0.f;
+        continue;
+      }
+      float p[TH_MAXH], g[TH_MAXH];
+#pragma unroll
+      for (int h = 0; h < TH_MAXH; ++h) {
         const bool ok = h < H && j < Nk;
         const int64_t o = ((b * H + h) * N + i) * ld + j;
-        s[h][c] = ok ? ldf(S + o) : 0.f;
-        p[h][c] = ok ? ldf(P + o) : 0.f;
-        g[h][c] = ok ? ldf(dPm + o) : 0.f;        // dL/dP'
+        p[h] = ok ? ldf(P + o) : 0.f;
+        g[h] = ok ? ldf(dPm + o) : 0.f;            // dL/dP'
       }
-    // through proj_w: dP[hp] = sum_ho Ww[ho][hp] dP'[ho];  dWw[ho][hp] += dP'[ho] * P[hp]
-    float dp[TH_MAXH][TH_MAXC];
+      // through proj_w: dP[hp] = sum_ho Ww[ho][hp] dP'[ho];  dWw[ho][hp] += dP'[ho] * P[hp]
 #pragma unroll
-    for (int hp = 0; hp < TH_MAXH; ++hp)
-#pragma unroll
-      for (int c = 0; c < TH_MAXC; ++c) {
+      for (int hp = 0; hp < TH_MAXH; ++hp) {
         float a = 0.f;
 #pragma unroll
         for (int ho = 0; ho < TH_MAXH; ++ho)
-          if (ho < H && hp < H) a = fmaf(Ww[ho * H + hp], g[ho][c], a);
+          if (ho < H && hp < H) a = fmaf(Ww[ho * H + hp], g[ho], a);
         dp[hp][c] = a;
+        dot[hp] = fmaf(a, p[hp], dot[hp]);
       }
 #pragma unroll
-    for (int ho = 0; ho < TH_MAXH; ++ho)
+      for (int ho = 0; ho < TH_MAXH; ++ho) {
+        abw[ho] += g[ho];
 #pragma unroll
-      for (int c = 0; c < TH_MAXC; ++c) {
-        abw[ho] += g[ho][c];
-#pragma unroll
-        for (int hp = 0; hp < TH_MAXH; ++hp) aWw[ho][hp] = fmaf(g[ho][c], p[hp][c], aWw[ho][hp]);
+        for (int hp = 0; hp < TH_MAXH; ++hp) aWw[ho][hp] = fmaf(g[ho], p[hp], aWw[ho][hp]);
       }
-    // through the softmax: dS'[hp] = P[hp] * (dP[hp] - sum_j dP[hp] P[hp])
-#pragma unroll
-    for (int hp = 0; hp < TH_MAXH; ++hp) {
-      float dot = 0.f;
-#pragma unroll
-      for (int c = 0; c < TH_MAXC; ++c) dot = fmaf(dp[hp][c], p[hp][c], dot);
-      dot = wave_sum(dot);
-#pragma unroll
-      for (int c = 0; c < TH_MAXC; ++c) dp[hp][c] = p[hp][c] * (dp[hp][c] - dot);   // now dS'
     }
-    // through proj_l: dS[h] = sum_hp Wl[hp][h] dS'[hp];  dWl[hp][h] += dS'[hp] * S[h]
 #pragma unroll
-    for (int hp = 0; hp < TH_MAXH; ++hp)
+    for (int hp = 0; hp < TH_MAXH; ++hp) dot[hp] = wave_sum(dot[hp]);
 #pragma unroll
-      for (int c = 0; c < TH_MAXC; ++c) {
-        abl[hp] += dp[hp][c];
+    for (int c = 0; c < TH_MAXC; ++c) {
+      const int j = c * 64 + lane;
+      if (c * 64 >= Nk) continue;
+      float p[TH_MAXH], sv[TH_MAXH], ds[TH_MAXH];
 #pragma unroll
-        for (int h = 0; h < TH_MAXH; ++h) aWl[hp][h] = fmaf(dp[hp][c], s[h][c], aWl[hp][h]);
+      for (int h = 0; h < TH_MAXH; ++h) {
+        const bool ok = h < H && j < Nk;
+        const int64_t o = ((b * H + h) * N + i) * ld + j;
+        p[h] = ok ? ldf(P + o) : 0.f;
+        sv[h] = ok ? ldf(S + o) : 0.f;
+      }
+      // through the softmax: dS'[hp] = P[hp] * (dP[hp] - sum_j dP[hp] P[hp])
+#pragma unroll
+      for (int hp = 0; hp < TH_MAXH; ++hp) ds[hp] = p[hp] * (dp[hp][c] - dot[hp]);
+      // through proj_l: dS[h] = sum_hp Wl[hp][h] dS'[hp];  dWl[hp][h] += dS'[hp] * S[h]
+#pragma unroll
+      for (int hp = 0; hp < TH_MAXH; ++hp) {
+        abl[hp] += ds[hp];
+#pragma unroll
+        for (int h = 0; h < TH_MAXH; ++h) aWl[hp][h] = fmaf(ds[hp], sv[h], aWl[hp][h]);
       }
 #pragma unroll
-    for (int h = 0; h < TH_MAXH; ++h) {
-      if (h >= H) break;
-#pragma unroll
-      for (int c = 0; c < TH_MAXC; ++c) {
+      for (int h = 0; h < TH_MAXH; ++h) {
+        if (h >= H) break;
         float a = 0.f;
 #pragma unroll
         for (int hp = 0; hp < TH_MAXH; ++hp)
-          if (hp < H) a = fmaf(Wl[hp * H + h], dp[hp][c], a);
-        const int j = c * 64 + lane;
+          if (hp < H) a = fmaf(Wl[hp * H + h], ds[hp], a);
         if (j < Nk) dS[((b * H + h) * N + i) * ld + j] = from_f32<T>(a);
       }
     }
