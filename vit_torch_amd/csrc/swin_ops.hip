@@ -76,6 +76,183 @@ __global__ __launch_bounds__(256) void win_attn_fwd_kernel(const T* __restrict__
   }
 }
 
+
+// ------------------------------------------------------------ MFMA path ---
+// bf16, hd = 32, N <= 64 (every Swin variant at window 7): ONE WAVE per (window, head),
+// v_mfma_f32_16x16x32_bf16 with K = 32 = the head dim, so a 16x16 score tile is one MFMA.
+//   S^T[key][q] = K Q^T      A = K rows, B = Q rows, both straight from global memory
+//                            (a token row of one head is 64 contiguous bytes);
+//                            the lane owns query q = 16*qb + (lane & 15) and keys
+//                            16*kb + 4*(lane >> 4) + r: softmax statistics are lane-local
+//                            plus two cross-group shuffles
+//   O^T[d][q]  = V^T P^T     B = the score accumulators themselves: k-step s takes the
+//                            tiles kb = 2s, 2s+1, so the k slot order is (kb&1)*16 + 4g + r,
+//                            and V^T is read from a [key][d] LDS image (96-B pitch) with
+//                            ds_read_b64_tr_b16 in that same order
+struct __attribute__((packed, aligned(4))) F4U { float v[4]; };   // 4-B aligned 16-B load
+
+constexpr int WP = 96;                 // LDS pitch of a staged [64 rows][32 bf16] image
+constexpr float NEG_BIG = -1e30f;
+
+// operand fragment (A or B) of rows = tokens: lane (i = lane&15, g = lane>>4) gets
+// X[token(16*blk + i)][8g .. 8g+7]; rows >= N are clamped (their results are masked/unused)
+__device__ __forceinline__ bf16x8 win_row_frag(const bf16* base, int64_t ts, const WinGeom& geo, int64_t bw,
+                                               int blk, int N, int lane) {
+  const int r = min(blk * 16 + (lane & 15), N - 1);
+  return *reinterpret_cast<const bf16x8*>(base + win_token(geo, bw, r) * ts + 8 * (lane >> 4));
+}
+// stage [64 rows][32] bf16 of one head into a wave-private LDS image (rows >= N zero)
+__device__ __forceinline__ void win_stage(char* img, const bf16* base, int64_t ts, const WinGeom& geo, int64_t bw,
+                                          int N, int lane) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int p = lane + 64 * t, row = p >> 2, c = p & 3;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
+    if (row < N) v = *reinterpret_cast<const bf16x8*>(base + win_token(geo, bw, row) * ts + 8 * c);
+    *reinterpret_cast<bf16x8*>(img + row * WP + c * 16) = v;
+  }
+}
+// A/B fragment whose k runs over the ROWS of a staged image, in the slot order
+// k(g, j) = k0 + 16*(j >> 2) + 4*g + (j & 3) (the order accumulator tiles present their rows)
+__device__ __forceinline__ bf16x8 win_tr_frag(const char* img, int pitch, int k0, int c0, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  const char* p = img + (k0 + 4 * g + (i >> 2)) * pitch + (c0 + 4 * (i & 3)) * 2;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, p));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, p + 16 * pitch));
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+__device__ __forceinline__ bf16x8 pack_tiles(const f32x4& a, const f32x4& b) {
+  bf16x8 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { r[e] = (bf16)a[e]; r[4 + e] = (bf16)b[e]; }
+  return r;
+}
+// scaled scores + relative-position bias + shift mask of tile (kb, qb) for this lane's query;
+// keys >= N get a large negative value
+__device__ __forceinline__ f32x4 win_bias_tile(const f32x4& st, float scale, const float* __restrict__ brow,
+                                               const float* __restrict__ mrow, int kb, int g, int N) {
+  f32x4 o;
+  const int key0 = kb * 16 + 4 * g;
+  if (key0 + 4 <= N) {
+    const F4U b = *reinterpret_cast<const F4U*>(brow + key0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = fmaf(st[r], scale, b.v[r]);
+    if (mrow) {
+      const F4U m = *reinterpret_cast<const F4U*>(mrow + key0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] += m.v[r];
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = key0 + r;
+      o[r] = key < N ? fmaf(st[r], scale, brow[key]) + (mrow ? mrow[key] : 0.f) : NEG_BIG;
+    }
+  }
+  return o;
+}
+
+__global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                               float* __restrict__ lse, const float* __restrict__ bias,
+                                                               const float* __restrict__ mask, WinGeom geo, int H, int N,
+                                                               float scale, int64_t tasks) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * 64 * WP];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t task = (int64_t)blockIdx.x * 4 + w;
+  if (task >= tasks) return;                       // no barriers below: waves are independent
+  const int64_t bw = task / H;
+  const int h = (int)(task % H);
+  const int i = lane & 15, g = lane >> 4;
+  const int64_t ts = (int64_t)3 * H * 32;
+  const bf16* qb_ = qkv + h * 32;
+  const bf16* kb_ = qkv + (H + h) * 32;
+  const bf16* vb_ = qkv + (2 * H + h) * 32;
+  char* Vs = smem + w * 64 * WP;
+  win_stage(Vs, vb_, ts, geo, bw, N, lane);
+  bf16x8 qf[4], kf[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    qf[b] = win_row_frag(qb_, ts, geo, bw, b, N, lane);
+    kf[b] = win_row_frag(kb_, ts, geo, bw, b, N, lane);
+  }
+  f32x4 st[4][4];                                  // [kb][qb]
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      st[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb], qf[qb], z, 0, 0, 0);
+    }
+  const float* mwin = mask ? mask + (bw % geo.nW) * (int64_t)N * N : nullptr;
+  float rinv[4];
+#pragma unroll
+  for (int qb = 0; qb < 4; ++qb) {
+    const int q = min(qb * 16 + i, N - 1);
+    const float* brow = bias + ((int64_t)h * N + q) * N;
+    const float* mrow = mwin ? mwin + (int64_t)q * N : nullptr;
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      st[kb][qb] = win_bias_tile(st[kb][qb], scale, brow, mrow, kb, g, N);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kb][qb][r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __expf(st[kb][qb][r] - mx);
+        st[kb][qb][r] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    rinv[qb] = 1.f / sum;
+    if (g == 0 && qb * 16 + i < N) lse[(bw * H + h) * N + qb * 16 + i] = mx + __logf(sum);
+  }
+  // O^T[d][q] = sum_key V^T[d][key] P^T[key][q]; the probabilities are normalised at the end
+  f32x4 o[2][4];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) o[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    bf16x8 vt[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db) vt[db] = win_tr_frag(Vs, WP, 32 * s, 16 * db, lane);
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+      const bf16x8 pf = pack_tiles(st[2 * s][qb], st[2 * s + 1][qb]);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt[db], pf, o[db][qb], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int qb = 0; qb < 4; ++qb) {
+    const int q = qb * 16 + i;
+    if (q < N) {
+      bf16* orow = out + win_token(geo, bw, q) * (int64_t)H * 32 + h * 32;
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        bf16x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (bf16)(o[db][qb][r] * rinv[qb]);
+        *reinterpret_cast<bf16x4*>(orow + db * 16 + 4 * g) = v;
+      }
+    }
+  }
+}
+
 // dQ + delta + dBias (per-window partial): wave per query row
 template <typename T>
 __global__ __launch_bounds__(256) void win_attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
@@ -234,6 +411,9 @@ __global__ void token_mean_bwd_kernel(const float* __restrict__ dout, T* __restr
 
 }  // namespace
 
+static int g_win_mfma = -1;   // diagnostic / test hook: 0 = fp32 vector kernels only, else MFMA where it applies
+extern "C" void vitmi_debug_win_attn_mfma(int mode) { g_win_mfma = mode; }
+
 static int win_check(int64_t Bw, int64_t H, int64_t N, int64_t hd, int64_t Himg, int64_t Wimg, int64_t ws, int64_t shift, const char* who) {
   VITMI_REQUIRE(Bw > 0 && H > 0 && H <= 65535, VITMI_E_BADARG, "%s: bad batch / heads", who);
   VITMI_REQUIRE(N == ws * ws && N <= 64 && hd >= 1 && hd <= 64, VITMI_E_SHAPE, "%s: window tokens %lld (<=64) / head dim %lld (<=64)", who, (long long)N, (long long)hd);
@@ -250,6 +430,12 @@ extern "C" int vitmi_win_attn_fwd(const void* qkv, void* out, float* lse, const 
   if (rc) return rc;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   WinGeom g{(int)Himg, (int)Wimg, (int)ws, (int)shift, (int)(Wimg / ws), (int)((Himg / ws) * (Wimg / ws))};
+  if (dtype == VITMI_BF16 && hd == 32 && g_win_mfma != 0 && is_aligned(qkv, 16) && is_aligned(out, 8)) {
+    const int64_t tasks = Bw * H;
+    hipLaunchKernelGGL(win_attn_fwd_mfma_kernel, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, stream,
+                       (const bf16*)qkv, (bf16*)out, lse, bias, mask, g, (int)H, (int)N, scale, tasks);
+    return vitmi_check_launch("win_attn_fwd_mfma_kernel");
+  }
   dim3 grid((unsigned)Bw, (unsigned)H);
   const size_t lds = 3 * 64 * (hd + 1) * sizeof(float);
   if (dtype == VITMI_BF16)
