@@ -253,6 +253,226 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(const bf16* __re
   }
 }
 
+
+// Backward, same mapping (one wave per (window, head)); a wave keeps ONE head and walks
+// windows, so the relative-position-bias gradient (a sum over all windows of a head)
+// accumulates in registers and is written once per wave as a partial [N][N] tile.
+//   S^T = K Q^T, dP^T = V dO^T           operands straight from global rows
+//   P^T = exp(S^T - lse), delta = sum_key P dP, dS^T = P (dP - delta)     lane-local (+2 shuffles)
+//   dV^T += dO^T P, dK^T += Q^T dS        contraction over queries: P / dS go through a
+//                                         wave-private LDS tile [q][key] (160-B pitch) and come
+//                                         back as B operands by ds_read_b64_tr_b16; dO^T / Q^T
+//                                         from [row][d] images the same way
+//   dQ^T += K^T dS^T                      B operand = the dS accumulators themselves
+constexpr int TP = 160;                // pitch of the [64 q][64 key] bf16 tile
+constexpr int WIN_BWD_LDS = 3 * 64 * WP + 64 * TP;     // Q, K, dO images + tile, per wave
+
+__device__ __forceinline__ void win_store_T(bf16* dst, const f32x4& acc, float mul, int g) {
+  bf16x4 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = (bf16)(acc[r] * mul);
+  *reinterpret_cast<bf16x4*>(dst + 4 * g) = v;
+}
+
+__global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const bf16* __restrict__ qkv,
+                                                               const bf16* __restrict__ dout,
+                                                               const float* __restrict__ lse,
+                                                               const float* __restrict__ bias,
+                                                               const float* __restrict__ mask,
+                                                               bf16* __restrict__ dqkv, float* __restrict__ dbias_part,
+                                                               WinGeom geo, int H, int N, float scale, int64_t Bw,
+                                                               int nwaves) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wid = blockIdx.x * 4 + w;
+  if (wid >= nwaves) return;                       // waves are independent: no barriers below
+  const int h = wid % H;
+  const int wstep = nwaves / H;
+  const int i = lane & 15, g = lane >> 4;
+  const int64_t ts = (int64_t)3 * H * 32, os = (int64_t)H * 32;
+  char* Qs = smem + w * WIN_BWD_LDS;
+  char* Ks = Qs + 64 * WP;
+  char* dOs = Ks + 64 * WP;
+  char* T = dOs + 64 * WP;
+  const bf16* qb_ = qkv + h * 32;
+  const bf16* kb_ = qkv + (H + h) * 32;
+  const bf16* vb_ = qkv + (2 * H + h) * 32;
+  const bf16* dob = dout + h * 32;
+
+  f32x4 dsum[4][4];                                // [kb][qb] running d(score) of this head
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) dsum[kb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int64_t bw = wid / H; bw < Bw; bw += wstep) {
+    win_stage(Qs, qb_, ts, geo, bw, N, lane);
+    win_stage(Ks, kb_, ts, geo, bw, N, lane);
+    win_stage(dOs, dob, os, geo, bw, N, lane);
+    f32x4 st[4][4], dpt[4][4];
+    {
+      bf16x8 qf[4], kf[4], vf[4], dof[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        qf[b] = win_row_frag(qb_, ts, geo, bw, b, N, lane);
+        kf[b] = win_row_frag(kb_, ts, geo, bw, b, N, lane);
+        vf[b] = win_row_frag(vb_, ts, geo, bw, b, N, lane);
+        dof[b] = win_row_frag(dob, os, geo, bw, b, N, lane);
+      }
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          st[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb], qf[qb], z, 0, 0, 0);
+          dpt[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kb], dof[qb], z, 0, 0, 0);
+        }
+    }
+    const float* mwin = mask ? mask + (bw % geo.nW) * (int64_t)N * N : nullptr;
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+      const int q = min(qb * 16 + i, N - 1);
+      const bool qok = qb * 16 + i < N;
+      const float* brow = bias + ((int64_t)h * N + q) * N;
+      const float* mrow = mwin ? mwin + (int64_t)q * N : nullptr;
+      const float l = lse[(bw * H + h) * N + q];
+      float del = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const f32x4 sc = win_bias_tile(st[kb][qb], scale, brow, mrow, kb, g, N);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = qok ? __expf(sc[r] - l) : 0.f;     // keys >= N: exp(-1e30 - l) = 0
+          st[kb][qb][r] = p;
+          del = fmaf(p, dpt[kb][qb][r], del);
+        }
+      }
+      del += __shfl_xor(del, 16, 64);
+      del += __shfl_xor(del, 32, 64);
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float ds = st[kb][qb][r] * (dpt[kb][qb][r] - del);
+          dpt[kb][qb][r] = ds;                     // now dS^T
+          dsum[kb][qb][r] += ds;
+        }
+    }
+    // ---- P -> tile [q][key]; dV^T[d][key] = sum_q dO^T[d][q] P[q][key]
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+        win_store_T(reinterpret_cast<bf16*>(T + (qb * 16 + i) * TP) + kb * 16, st[kb][qb], 1.f, g);
+    {
+      f32x4 dv[2][4];
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) dv[db][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 a[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db) a[db] = win_tr_frag(dOs, WP, 32 * s, 16 * db, lane);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          const bf16x8 b = win_tr_frag(T, TP, 32 * s, 16 * kb, lane);
+#pragma unroll
+          for (int db = 0; db < 2; ++db) dv[db][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[db], b, dv[db][kb], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const int key = kb * 16 + i;
+        if (key < N) {
+          bf16* row = dqkv + win_token(geo, bw, key) * ts + (2 * H + h) * 32;
+#pragma unroll
+          for (int db = 0; db < 2; ++db) win_store_T(row + db * 16, dv[db][kb], 1.f, g);
+        }
+      }
+    }
+    // ---- dS -> the same tile; dK^T[d][key] = scale * sum_q Q^T[d][q] dS[q][key]
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+        win_store_T(reinterpret_cast<bf16*>(T + (qb * 16 + i) * TP) + kb * 16, dpt[kb][qb], 1.f, g);
+    {
+      f32x4 dk[2][4];
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) dk[db][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 a[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db) a[db] = win_tr_frag(Qs, WP, 32 * s, 16 * db, lane);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          const bf16x8 b = win_tr_frag(T, TP, 32 * s, 16 * kb, lane);
+#pragma unroll
+          for (int db = 0; db < 2; ++db) dk[db][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[db], b, dk[db][kb], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const int key = kb * 16 + i;
+        if (key < N) {
+          bf16* row = dqkv + win_token(geo, bw, key) * ts + (H + h) * 32;
+#pragma unroll
+          for (int db = 0; db < 2; ++db) win_store_T(row + db * 16, dk[db][kb], scale, g);
+        }
+      }
+    }
+    // ---- dQ^T[d][q] = scale * sum_key K^T[d][key] dS^T[key][q]   (B = the dS accumulators)
+    {
+      f32x4 dq[2][4];
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) dq[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 a[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db) a[db] = win_tr_frag(Ks, WP, 32 * s, 16 * db, lane);
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+          const bf16x8 b = pack_tiles(dpt[2 * s][qb], dpt[2 * s + 1][qb]);
+#pragma unroll
+          for (int db = 0; db < 2; ++db) dq[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[db], b, dq[db][qb], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int qb = 0; qb < 4; ++qb) {
+        const int q = qb * 16 + i;
+        if (q < N) {
+          bf16* row = dqkv + win_token(geo, bw, q) * ts + h * 32;
+#pragma unroll
+          for (int db = 0; db < 2; ++db) win_store_T(row + db * 16, dq[db][qb], scale, g);
+        }
+      }
+    }
+  }
+  // partial d(bias): row wid / H of [nwaves / H][H][N][N]
+  float* prow = dbias_part + ((int64_t)(wid / H) * H + h) * N * N;
+#pragma unroll
+  for (int qb = 0; qb < 4; ++qb) {
+    const int q = qb * 16 + i;
+    if (q >= N) continue;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kb * 16 + 4 * g + r;
+        if (key < N) prow[q * N + key] = dsum[kb][qb][r];
+      }
+  }
+}
+
 // dQ + delta + dBias (per-window partial): wave per query row
 template <typename T>
 __global__ __launch_bounds__(256) void win_attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
@@ -447,7 +667,10 @@ extern "C" int vitmi_win_attn_fwd(const void* qkv, void* out, float* lse, const 
 }
 
 extern "C" size_t vitmi_win_attn_bwd_workspace(int64_t Bw, int64_t H, int64_t N) {
-  return (size_t)(Bw * H * N) * sizeof(float) + (size_t)(Bw * H * N * N) * sizeof(float);
+  // delta [Bw,H,N] + per-window (vector kernels) or per-wave (MFMA kernel, <= 1024 waves)
+  // partial d(bias) tiles
+  int64_t rows = Bw > 1024 / (H > 0 ? H : 1) + 1 ? Bw : 1024 / (H > 0 ? H : 1) + 1;
+  return (size_t)(Bw * H * N) * sizeof(float) + (size_t)(rows * H * N * N) * sizeof(float);
 }
 
 // dbias [H,N,N] fp32 (overwritten) = sum over windows of d(score)
@@ -463,6 +686,24 @@ extern "C" int vitmi_win_attn_bwd(const void* qkv, const void* dout, const float
   WinGeom g{(int)Himg, (int)Wimg, (int)ws, (int)shift, (int)(Wimg / ws), (int)((Himg / ws) * (Wimg / ws))};
   float* delta = reinterpret_cast<float*>(workspace);
   float* part = delta + Bw * H * N;
+  if (dtype == VITMI_BF16 && hd == 32 && g_win_mfma != 0 && is_aligned(qkv, 16) && is_aligned(dout, 16) && is_aligned(dqkv, 8)) {
+    // one head per wave, ~4 waves per CU; nwaves a multiple of H, at most one wave per task
+    int64_t per_head = 1024 / H;
+    if (per_head > Bw) per_head = Bw;
+    if (per_head < 1) per_head = 1;
+    const int nwaves = (int)(per_head * H);
+    auto kern = win_attn_bwd_mfma_kernel;
+    static bool attr = false;
+    if (!attr) {
+      hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WIN_BWD_LDS);
+      if (err != hipSuccess) return vitmi_fail((int)err, "win_attn_bwd: cannot raise dynamic LDS: %s", hipGetErrorString(err));
+      attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 4 * WIN_BWD_LDS, stream, (const bf16*)qkv,
+                       (const bf16*)dout, lse, bias, mask, (bf16*)dqkv, part, g, (int)H, (int)N, scale, Bw, nwaves);
+    if ((rc = vitmi_check_launch("win_attn_bwd_mfma_kernel"))) return rc;
+    return vitmi_reduce_rows(part, (int)per_head, H * N * N, H * N * N, dbias, stream);
+  }
   dim3 grid((unsigned)Bw, (unsigned)H);
   const size_t lds = 4 * 64 * (hd + 1) * sizeof(float);
   if (dtype == VITMI_BF16) {
