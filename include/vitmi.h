@@ -100,7 +100,7 @@ typedef struct vitmi_gemm_desc {
    * * gamma[n]*(acc+bias) — DropPath's per-sample keep/keep_prob (timm DropPath as used at
    * models/swin.py:203,267-268) with rows_per_group = tokens per image.  NULL -> 1. */
   const float* rowscale; int64_t rows_per_group;
-  /* EPI_DGELU on the aligned (256x256-tile) path only: optional fp32 [M/128][N] (ld = N);
+  /* EPI_DGELU on the bf16 tile paths only: optional fp32 [ceil(M/128)][N] (ld = N);
    * row r receives the column sums of the fp32 epilogue results of rows [128r, 128r+128).
    * Their sum over r (vitmi_colsum) is the bias gradient of the Linear whose
    * pre-activation is AUX (torch.nn.Linear backward, db = sum_rows dH) — fused here so dH

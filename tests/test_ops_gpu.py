@@ -479,6 +479,13 @@ def test_gemm_ragged_epilogues(ops):
     Dg = torch.empty((M, N), device="cuda", dtype=bt)
     ops.gemm(A, Bt, Dg, b_kmajor=False, epilogue=EPI_DGELU, aux=dev(aux, bt), impl=GEMM_FAST)
     assert_close("dgelu", Dg, acc * gelu_grad(aux), TOL[bt])
+    # fused bias gradient on a ragged shape: partial rows of 128, the last one short
+    part = torch.full(((M + 127) // 128, N), float("nan"), device="cuda")
+    Dg2 = torch.empty_like(Dg)
+    ops.gemm(A, Bt, Dg2, b_kmajor=False, epilogue=EPI_DGELU, aux=dev(aux, bt), impl=GEMM_FAST, colsum_part=part)
+    assert torch.equal(Dg2, Dg)
+    want = F.pad(acc * gelu_grad(aux), (0, 0, 0, part.shape[0] * 128 - M)).view(-1, 128, N).sum(1)
+    assert_close("dgelu.colsum_part(ragged)", part, want, 2e-3)
     # weight-gradient form with split-K: [N x K_out] = dy^T x over M tokens
     W = torch.empty((N, K), device="cuda")
     Mk = M // 32 * 32 - 32                           # 960 tokens: an odd number of 32-deep slabs per split

@@ -660,7 +660,7 @@ static bool combo_built(const GemmArgs& g) {
 bool gemm_fast_supported(const GemmArgs& g, int in_bf16) {
   if (!in_bf16) return false;
   if (!use_tile2(g) && (g.M % BM || g.N % BN || g.K % BK)) return false;
-  if (g.e.colsum_part && (use_tile2(g) || g.e.mode != VITMI_EPI_DGELU || !is_aligned(g.e.colsum_part, 16))) return false;
+  if (g.e.colsum_part && (g.e.mode != VITMI_EPI_DGELU || !is_aligned(g.e.colsum_part, 16))) return false;
   if (g.M / BM * (g.N / BN) > (1 << 30)) return false;
   if (!combo_built(g)) return false;
   const EpiArgs& e = g.e;

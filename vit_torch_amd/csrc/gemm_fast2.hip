@@ -128,6 +128,22 @@ __device__ __forceinline__ void wait_vm6(bool next_in_flight) {
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// (the DGELU column sums of gemm_fast.hip, for ragged shapes: rows >= M were never added)
+template <int MODE, bool SPLITK, int W, int LPR>
+__device__ __forceinline__ void colsum_part2(const GemmArgs& g, float (&cs)[W], int64_t m0, int wm, int64_t ncol,
+                                             bool col_ok, int rr) {
+  if constexpr (MODE == VITMI_EPI_DGELU && !SPLITK) {
+    if (g.e.colsum_part) {
+#pragma unroll
+      for (int i = 0; i < W; ++i) {
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1) cs[i] += __shfl_xor(cs[i], off, 64);
+      }
+      if (rr == 0 && col_ok && m0 + wm * 128 < g.M) storev<float, W>(g.e.colsum_part + ((m0 >> 7) + wm) * g.N + ncol, cs);
+    }
+  }
+}
+
 template <bool A_KM, bool B_KM, int MODE, typename TC, bool SPLITK>
 __global__ __launch_bounds__(NT2, 2) void gemm_fast2_kernel(GemmArgs g, int tiles_n, int nwg, int ntiles,
                                                             int ksps, float* ws) {
@@ -226,6 +242,9 @@ __global__ __launch_bounds__(NT2, 2) void gemm_fast2_kernel(GemmArgs g, int tile
   }
   constexpr int NJ = 16 / RPI;                     // row groups per strip
   const bool side = !SPLITK && epi_has_side<MODE, TC>(g.e);
+  float cs[W];                                     // DGELU: column sums of this lane's rows
+#pragma unroll
+  for (int i = 0; i < W; ++i) cs[i] = 0.f;
   float sx[2][NJ][W];                              // side inputs: this strip and the next
 #pragma unroll
   for (int j = 0; j < NJ; ++j)
@@ -263,11 +282,17 @@ __global__ __launch_bounds__(NT2, 2) void gemm_fast2_kernel(GemmArgs g, int tile
       if (col_ok && m < g.M) {                     // surplus rows / columns of a ragged tile
         if constexpr (SPLITK)
           storev<float, W>(ws + ((int64_t)split * g.M + m) * g.N + ncol, v);
-        else
+        else {
           epi_row<MODE, TC, W>(g.e, m, ncol, v, bias_r, gamma_r, sx[mi & 1][j]);
+          if constexpr (MODE == VITMI_EPI_DGELU) {
+#pragma unroll
+            for (int i = 0; i < W; ++i) cs[i] += v[i];
+          }
+        }
       }
     }
   }
+  colsum_part2<MODE, SPLITK, W, LPR>(g, cs, m0, wm, ncol, col_ok, rr);
 }
 
 __global__ void splitk_reduce2_kernel(const float* __restrict__ ws, int splits, EpiArgs e, int64_t M, int64_t N) {

@@ -7,9 +7,9 @@
 //    added to the scores in registers.
 //  * relative-position-bias gather / gradient scatter (:126-129), PatchMerging gather /
 //    scatter (:317-323), token mean (AdaptiveAvgPool1d, :584).
-// First version of this row: fp32 vector math for both activation dtypes (N = 49 tokens and
-// hd = 32 leave the MFMA shapes mostly empty; an MFMA version is the next step).
-// One workgroup = one (window, head); 4 waves; window tokens N <= 64, hd <= 64.
+// Two implementations: fp32 vector kernels (any hd <= 64, both dtypes: the parity mode) with
+// one workgroup per (window, head), and the bf16 MFMA kernels for hd = 32 (every Swin variant
+// at window 7) with one WAVE per (window, head) — "MFMA path" below.
 #include "common.h"
 
 namespace {
@@ -574,16 +574,19 @@ __global__ void relpos_gather_kernel(const float* __restrict__ table, const int6
   const int h = t / NN, ij = t % NN;
   bias[t] = table[index[ij] * H + h];
 }
-// dtable[t][h] = sum_{ij: index[ij]==t} dbias[h][ij]   (deterministic: one thread per entry)
-__global__ void relpos_scatter_kernel(const float* __restrict__ dbias, const int64_t* __restrict__ index,
-                                      float* __restrict__ dtable, int T, int H, int NN) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= T * H) return;
-  const int t = e / H, h = e % H;
-  float s = 0.f;
-  for (int ij = 0; ij < NN; ++ij)
-    if (index[ij] == t) s += dbias[(int64_t)h * NN + ij];
-  dtable[e] = s;
+// dtable[t][h] = sum_{ij: index[ij]==t} dbias[h][ij]: one workgroup per table row t, a wave
+// per head (strided), lanes over ij, fixed-order wave reduction (deterministic)
+__global__ __launch_bounds__(256) void relpos_scatter_kernel(const float* __restrict__ dbias,
+                                                            const int64_t* __restrict__ index,
+                                                            float* __restrict__ dtable, int T, int H, int NN) {
+  const int t = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int h = w; h < H; h += 4) {
+    float s = 0.f;
+    for (int ij = lane; ij < NN; ij += 64)
+      if (index[ij] == t) s += dbias[(int64_t)h * NN + ij];
+    s = wave_sum(s);
+    if (lane == 0) dtable[(int64_t)t * H + h] = s;
+  }
 }
 
 // PatchMerging gather (inverse = 0): out[b,(i,j), k*C + c] = x[b,(2i+dy_k, 2j+dx_k), c],
@@ -732,7 +735,7 @@ extern "C" int vitmi_relpos_bias(const float* table, const int64_t* index, float
     if (rc) return rc;
   }
   if (dbias && dtable) {
-    hipLaunchKernelGGL(relpos_scatter_kernel, dim3((unsigned)((T * H + 255) / 256)), dim3(256), 0, stream, dbias, index, dtable, (int)T, (int)H, NN);
+    hipLaunchKernelGGL(relpos_scatter_kernel, dim3((unsigned)T), dim3(256), 0, stream, dbias, index, dtable, (int)T, (int)H, NN);
     return vitmi_check_launch("relpos_scatter_kernel");
   }
   return 0;

@@ -98,7 +98,7 @@ def gemm(A, B, C_out, *, a_kmajor=True, b_kmajor=True, epilogue=EPI_STORE, bias=
         d.rowscale, d.rows_per_group = rowscale.data_ptr(), rows_per_group
     if colsum_part is not None:
         assert colsum_part.dtype == torch.float32 and colsum_part.is_contiguous()
-        assert tuple(colsum_part.shape) == (M // 128, N) and M % 128 == 0
+        assert tuple(colsum_part.shape) == ((M + 127) // 128, N)
         d.colsum_part = colsum_part.data_ptr()
     lib = load()
     need = lib.vitmi_gemm_workspace(C.byref(d))

@@ -28,7 +28,7 @@ import torch.nn as nn
 from . import ops
 from ._lib import EPI_BIAS_GELU, EPI_DGELU, EPI_RESIDUAL, GEMM_AUTO, VitmiError
 from .packing import ParamPack
-from .vit import Mlp, _DT, _EngineFn, _head_layers, _trunc_normal_, engine_gemm
+from .vit import Mlp, _DT, _EngineFn, _head_layers, _trunc_normal_, dgelu_gemm_with_bias_grad, engine_gemm
 
 
 def _relative_position_index(ws):
@@ -442,12 +442,12 @@ class SwinEngine:
                 Bw = B * (Hh // ws) * (Ww // ws)
                 Dh = mlp.fc1.out_features
                 dH = new(M, Dh, T)
-                self._gemm(Gb, self._w(mlp.fc2.weight), dH, b_kmajor=False, epilogue=EPI_DGELU, aux=pre)
+                fold = dgelu_gemm_with_bias_grad(self, Gb, self._w(mlp.fc2.weight), dH, pre, pk.g(mlp.fc1.bias))
                 self._gemm(Gb, hid, pk.g(mlp.fc2.weight), a_kmajor=False, b_kmajor=False)
                 dln2 = new(M, C, T)
                 self._gemm(dH, self._w(mlp.fc1.weight), dln2, b_kmajor=False)
                 self._gemm(dH, ln2, pk.g(mlp.fc1.weight), a_kmajor=False, b_kmajor=False)
-                ops.colsum(dH, pk.g(mlp.fc1.bias))
+                fold()
                 ops.layernorm_bwd(dln2, X1, mean2, rstd2, pk.f32(blk.norm2.weight), G, G, Gb,
                                   pk.g(blk.norm2.weight), pk.g(blk.norm2.bias), gsum=pk.g(a.proj.bias),
                                   gb_rowscale=rs1, rows_per_group=L, M=M, D=C)

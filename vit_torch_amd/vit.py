@@ -179,6 +179,23 @@ def engine_gemm(eng, A, B, C, **k):
     return C
 
 
+def dgelu_gemm_with_bias_grad(eng, Gb, W2, dH, pre, bias_grad):
+    """dH = (Gb @ W2) * gelu'(pre) and bias_grad = column sums of dH.  On the bf16 tile paths
+    the sums ride on the GEMM epilogue as per-128-row partials (a few MB, folded by colsum);
+    otherwise dH is summed by a separate pass.  Returns a thunk that performs the fold /
+    pass (callers may run it on a side stream)."""
+    M, Dh = dH.shape
+    K = Gb.shape[1]
+    fused = (dH.dtype == torch.bfloat16 and eng.gemm_impl == GEMM_AUTO and eng.profile is None
+             and ops.gemm_uses_fast(M, Dh, K, b_kmajor=False, epilogue=EPI_DGELU, colsum_part=True))
+    if fused:
+        part = torch.empty(((M + 127) // 128, Dh), dtype=torch.float32, device=dH.device)
+        eng._gemm(Gb, W2, dH, b_kmajor=False, epilogue=EPI_DGELU, aux=pre, colsum_part=part)
+        return lambda: ops.colsum(part, bias_grad)
+    eng._gemm(Gb, W2, dH, b_kmajor=False, epilogue=EPI_DGELU, aux=pre)
+    return lambda: ops.colsum(dH, bias_grad)
+
+
 class VitEngine:
     """Executes VisionTransformer forward / backward as a fixed kernel sequence.
 
