@@ -494,6 +494,45 @@ def test_gemm_ragged_epilogues(ops):
     assert_close("wgrad", W, dy.t() @ a[:Mk], 1e-4)
 
 
+def test_gemm_split_tail_matches_whole_tile_launch(ops, lib):
+    """591 tiles on 256 CUs = 2 full rounds + 79 tiles: the remainder is contracted in three
+    k-slices and finished by the row-wise epilogue kernel.  Same results (up to the fp32
+    summation order) as the one-launch path, for the plain store and the residual epilogue."""
+    import ctypes
+    from vit_torch_amd import _lib
+    from vit_torch_amd._lib import EPI_RESIDUAL, GEMM_FAST
+    raw = ctypes.CDLL(str(_lib.LIB_PATH))
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        pytest.skip("tile counts below are chosen for 256 CUs")
+    M, N, K = 197 * 256, 768, 768
+    bt = torch.bfloat16
+    A = (torch.randn(M, K, device="cuda") * 0.5).to(bt)
+    Bw = (torch.randn(N, K, device="cuda") * 0.05).to(bt)
+    Bt = Bw.t().contiguous()
+    bias = torch.randn(N, device="cuda")
+    R = torch.randn(M, N, device="cuda")
+    gam = torch.randn(N, device="cuda")
+    rsc = (torch.rand(256, device="cuda") > 0.3).float() * 1.25
+    outs = {}
+    for mode in (0, 1):
+        raw.vitmi_debug_gemm_tail(mode)
+        C1 = torch.empty((M, N), device="cuda", dtype=bt)
+        ops.gemm(A, Bw, C1, bias=bias, impl=GEMM_FAST)                                   # NT store
+        C2 = torch.empty((M, N), device="cuda", dtype=bt)
+        ops.gemm(A, Bt, C2, b_kmajor=False, impl=GEMM_FAST)                              # NN store
+        X = torch.empty((M, N), device="cuda")
+        F1 = torch.empty((M, N), device="cuda", dtype=bt)
+        ops.gemm(A, Bw, X, epilogue=EPI_RESIDUAL, bias=bias, R=R, gamma=gam, C2=F1, rowscale=rsc,
+                 rows_per_group=197, impl=GEMM_FAST)
+        outs[mode] = (C1, C2, X, F1)
+    raw.vitmi_debug_gemm_tail(-1)
+    for name, a, b in zip(("nt store", "nn store", "residual", "residual C2"), outs[0], outs[1]):
+        assert_close(name, b, a.float().cpu(), 8e-3 if b.dtype == bt else 1e-5)   # bf16: one ulp at the maximum
+    # and against fp32 math on a slice that lies in the tail tiles (last rows)
+    ref = (A[-512:].float() @ Bw.float().t() + bias).cpu()
+    assert_close("tail rows vs fp32", outs[1][0][-512:], ref, TOL[bt])
+
+
 def test_gemm_fast_epilogues(ops, pipe):
     from vit_torch_amd._lib import (EPI_BIAS_GELU, EPI_DGELU, EPI_PATCH_POS, EPI_RESIDUAL, GEMM_FAST)
     M, N, K = 512, 256, 192

@@ -219,7 +219,7 @@ __device__ __forceinline__ uint32_t frag_half(uint32_t off, int kh) {
 // buffer one phase AFTER the wait that retires it").
 template <bool A_KM, bool B_KM, int MODE, typename TC, bool SPLITK = false, int PIPE = 0>
 __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int tiles_n, int nwg,
-                                                             int ntiles, int ksps, float* ws) {
+                                                             int ntiles, int ksps, float* ws, int tile0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (A tile | B tile)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
   const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   // consecutive wg share the split (k range) and walk the tiles: operand panels stay in L2
   const int split = SPLITK ? wg / ntiles : 0;
-  const int tile = SPLITK ? wg % ntiles : wg;
+  const int tile = tile0 + (SPLITK ? wg % ntiles : wg);   // tile0: first tile of a partial launch
   const int64_t m0 = (int64_t)(tile / tiles_n) * BM;
   const int64_t n0 = (int64_t)(tile % tiles_n) * BN;
 
@@ -551,6 +551,67 @@ inline void splitk_plan(int tiles, int nt, int* splits, int* ksps) {
   *splits = (nt + k - 1) / k;
 }
 
+// Tail tiles: C = epilogue(sum of the k-slices).  16 blocks of 256 threads per 256x256 tile:
+// block b of a tile covers rows 16b..16b+15, a thread W columns of one row (full lines).
+template <int MODE, typename TC>
+__global__ __launch_bounds__(256) void tail_epilogue_kernel(const float* __restrict__ ws, int splits, EpiArgs e,
+                                                           int64_t M, int64_t N, int tiles_n, int tile0) {
+  constexpr int W = sizeof(TC) == 2 ? 8 : 4;
+  constexpr int TPR = 256 / W;                       // threads per 256-column row
+  constexpr int RPB = 256 / TPR;                     // rows per pass of the block
+  const int tile = tile0 + blockIdx.x / 16;
+  const int64_t m0 = (int64_t)(tile / tiles_n) * BM + (blockIdx.x % 16) * 16;
+  const int64_t n = (int64_t)(tile % tiles_n) * BN + (threadIdx.x % TPR) * W;
+  float b[W], gm[W];
+#pragma unroll
+  for (int i = 0; i < W; ++i) { b[i] = 0.f; gm[i] = 1.f; }
+  if (e.bias) loadv<float, W>(e.bias + n, b);
+  if (MODE == VITMI_EPI_RESIDUAL && e.gamma) loadv<float, W>(e.gamma + n, gm);
+  for (int r = threadIdx.x / TPR; r < 16; r += RPB) {
+    const int64_t m = m0 + r;
+    float v[W];
+    loadv<float, W>(ws + m * N + n, v);
+    for (int s = 1; s < splits; ++s) {
+      float t[W];
+      loadv<float, W>(ws + ((int64_t)s * M + m) * N + n, t);
+#pragma unroll
+      for (int i = 0; i < W; ++i) v[i] += t[i];
+    }
+    float x[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) x[i] = 0.f;
+    if (epi_has_side<MODE, TC>(e)) epi_side<MODE, TC, W>(e, m, n, x);
+    epi_row<MODE, TC, W>(e, m, n, v, b, gm, x);
+  }
+}
+
+static int g_tail_override = -1;
+// diagnostic / test hook: 0 = never split the tail, 1 = whenever the shape allows, -1 = default heuristic
+extern "C" void vitmi_debug_gemm_tail(int mode) { g_tail_override = mode; }
+constexpr int TAIL_SPLITS = 3;
+// tail_plan: is the remainder round worth slicing?  Needs a workspace of TAIL_SPLITS full
+// M x N fp32 slabs (only the tail tiles' part is touched), no fused column sums, and a
+// contraction long enough that a third of it still amortises the partial-tile traffic.
+static bool tail_plan_shape(const GemmArgs& g, int nwg, int* rem, int* splits, int* ksps, bool forced) {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  const int nt = (int)(g.K / BK);
+  const int r = nwg % cus;
+  if (nwg <= cus || r == 0 || r * TAIL_SPLITS > cus) return false;
+  if (!forced && nt < 36) return false;
+  if (nt < 2 * TAIL_SPLITS) return false;
+  *rem = r;
+  *splits = TAIL_SPLITS;
+  *ksps = (nt + TAIL_SPLITS - 1) / TAIL_SPLITS;
+  if ((*splits - 1) * *ksps >= nt) return false;      // every slice must be non-empty
+  return true;
+}
+static bool tail_plan(const GemmArgs& g, int nwg, int* rem, int* splits, int* ksps) {
+  if (g_tail_override == 0 || g.e.colsum_part || g.e.accumulate) return false;
+  if (!tail_plan_shape(g, nwg, rem, splits, ksps, g_tail_override == 1)) return false;
+  return g.ws != nullptr && g.ws_bytes >= (size_t)TAIL_SPLITS * g.M * g.N * sizeof(float);
+}
+
 static int g_pipe_override = -1;
 // diagnostic / test hook: force the main-loop variant (0, 1, 2) or -1 = automatic
 extern "C" void vitmi_debug_gemm_pipe(int mode) { g_pipe_override = mode; }
@@ -593,7 +654,7 @@ int launch_p(const GemmArgs& g, hipStream_t stream) {
         attr_set_sk = true;
       }
       float* ws = reinterpret_cast<float*>(g.ws);
-      hipLaunchKernelGGL(kern, dim3(nwg * splits), dim3(NTHREADS), 2 * STAGE_BYTES, stream, g, tiles_n, nwg * splits, nwg, ksps, ws);
+      hipLaunchKernelGGL(kern, dim3(nwg * splits), dim3(NTHREADS), 2 * STAGE_BYTES, stream, g, tiles_n, nwg * splits, nwg, ksps, ws, 0);
       int rc = vitmi_check_launch("gemm_fast_kernel(split-K)");
       if (rc) return rc;
       const int64_t work = g.M * g.N / 4;
@@ -603,6 +664,33 @@ int launch_p(const GemmArgs& g, hipStream_t stream) {
       return vitmi_check_launch("splitk_reduce_kernel");
     }
   }
+  // ---- split tail: a launch of q full rounds plus a short remainder leaves most CUs idle
+  // for a whole tile time.  The remainder tiles are instead contracted in TAIL_SPLITS k-slices
+  // (one short round on all CUs, raw fp32 partial tiles to the workspace) and finished by a
+  // row-wise kernel that sums the slices in a fixed order and applies the epilogue.
+  if constexpr (MODE == VITMI_EPI_STORE || MODE == VITMI_EPI_RESIDUAL) {
+    int rem = 0, splits = 0, ksps = 0;
+    if (tail_plan(g, nwg, &rem, &splits, &ksps)) {
+      const int full = nwg - rem;
+      auto kmain = gemm_fast_kernel<A_KM, B_KM, MODE, TC, false, PIPE>;
+      auto ktail = gemm_fast_kernel<A_KM, B_KM, VITMI_EPI_STORE, float, true, PIPE>;
+      static bool attr_tail = false;
+      if (!attr_tail) {
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(kmain), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(ktail), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+        if (e1 != hipSuccess || e2 != hipSuccess) return vitmi_fail((int)(e1 != hipSuccess ? e1 : e2), "gemm_fast: cannot raise dynamic LDS");
+        attr_tail = true;
+      }
+      float* ws = reinterpret_cast<float*>(g.ws);
+      hipLaunchKernelGGL(kmain, dim3(full), dim3(NTHREADS), 2 * STAGE_BYTES, stream, g, tiles_n, full, full, 0, (float*)nullptr, 0);
+      int rc = vitmi_check_launch("gemm_fast_kernel(full rounds)");
+      if (rc) return rc;
+      hipLaunchKernelGGL(ktail, dim3(rem * splits), dim3(NTHREADS), 2 * STAGE_BYTES, stream, g, tiles_n, rem * splits, rem, ksps, ws, full);
+      if ((rc = vitmi_check_launch("gemm_fast_kernel(tail slices)"))) return rc;
+      hipLaunchKernelGGL((tail_epilogue_kernel<MODE, TC>), dim3(rem * 16), dim3(256), 0, stream, ws, splits, g.e, g.M, g.N, tiles_n, full);
+      return vitmi_check_launch("tail_epilogue_kernel");
+    }
+  }
   auto kern = gemm_fast_kernel<A_KM, B_KM, MODE, TC, false, PIPE>;
   static bool attr_set = false;   // per instantiation
   if (!attr_set) {
@@ -610,7 +698,7 @@ int launch_p(const GemmArgs& g, hipStream_t stream) {
     if (err != hipSuccess) return vitmi_fail((int)err, "gemm_fast: cannot raise dynamic LDS to %d: %s", 2 * STAGE_BYTES, hipGetErrorString(err));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(NTHREADS), 2 * STAGE_BYTES, stream, g, tiles_n, nwg, nwg, 0, (float*)nullptr);
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(NTHREADS), 2 * STAGE_BYTES, stream, g, tiles_n, nwg, nwg, 0, (float*)nullptr, 0);
   return vitmi_check_launch("gemm_fast_kernel");
 }
 
@@ -679,10 +767,19 @@ bool gemm_fast_supported(const GemmArgs& g, int in_bf16) {
 
 size_t gemm_fast_workspace(const GemmArgs& g) {
   if (use_tile2(g)) return gemm_fast2_workspace(g);
-  if (g.e.mode != VITMI_EPI_STORE || g.e.c_bf16) return 0;
-  int splits, ksps;
-  splitk_plan((int)(g.M / BM * (g.N / BN)), (int)(g.K / BK), &splits, &ksps);
-  return splits > 1 ? (size_t)splits * g.M * g.N * sizeof(float) : 0;
+  const int tiles = (int)(g.M / BM * (g.N / BN));
+  size_t need = 0;
+  if (g.e.mode == VITMI_EPI_STORE && !g.e.c_bf16) {
+    int splits, ksps;
+    splitk_plan(tiles, (int)(g.K / BK), &splits, &ksps);
+    if (splits > 1) need = (size_t)splits * g.M * g.N * sizeof(float);
+  }
+  if (need == 0 && (g.e.mode == VITMI_EPI_STORE || g.e.mode == VITMI_EPI_RESIDUAL) && g_tail_override != 0 &&
+      !g.e.colsum_part && !g.e.accumulate) {
+    int rem, splits, ksps;
+    if (tail_plan_shape(g, tiles, &rem, &splits, &ksps, g_tail_override == 1)) need = (size_t)TAIL_SPLITS * g.M * g.N * sizeof(float);
+  }
+  return need;
 }
 
 int gemm_fast_launch(const GemmArgs& g, hipStream_t s) {

@@ -451,7 +451,7 @@ class VitEngine:
             # sums, folded by a tiny colsum) whenever those kernels are the bf16 fast ones
             dH_part = None
             if fused_bias and ops.gemm_uses_fast(M, Dh, D, b_kmajor=False, epilogue=EPI_DGELU, colsum_part=True):
-                dH_part = torch.empty((M // 128, Dh), dtype=torch.float32, device=dev)
+                dH_part = torch.empty(((M + 127) // 128, Dh), dtype=torch.float32, device=dev)
             self._gemm(Gb, self._w(mlp.fc2.weight), dH, b_kmajor=False, epilogue=EPI_DGELU, aux=pre,
                        **({"colsum_part": dH_part} if dH_part is not None else {}))
             Gb_mlp = Gb
