@@ -68,14 +68,20 @@ template <int HD>
 __device__ __forceinline__ void prefetch_rows(bf16x8 (&r)[4], const bf16* g, int64_t ts, int row0,
                                               int rows, int N, int tid, int nthr) {
   constexpr int CPR = HD / 8;
+  // unconditional loads from clamped rows, zeroed afterwards: a branch around a load makes
+  // hipcc wait for each load separately (guide §5, trap 4(c))
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = tid + i * nthr;
+    const int gr = min(row0 + c / CPR, N - 1);
+    r[i] = *reinterpret_cast<const bf16x8*>(g + (int64_t)gr * ts + (c % CPR) * 8);
+  }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) r[i][e] = (bf16)0.f;
-    if (c < rows * CPR) {
-      const int gr = row0 + c / CPR;
-      if (gr < N) r[i] = *reinterpret_cast<const bf16x8*>(g + (int64_t)gr * ts + (c % CPR) * 8);
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + i * nthr;
+    if (c >= rows * CPR || row0 + c / CPR >= N) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[i][e] = (bf16)0.f;
     }
   }
 }
