@@ -30,7 +30,7 @@ for spec in specs:
     from vit_torch_amd import _lib
     raw = ctypes.CDLL(str(_lib.LIB_PATH))
     fl = 4.0 * B * H * N * N * hd
-    for cap in (8, 4, 8, 4):
+    for cap in (0, 4, 0, 4):
         raw.vitmi_debug_attn_fwd_waves(cap)
         tf = timed(lambda: ops.attn_fwd(qkv, O, lse, B, N, H, hd, scale))
         print(f"{spec}: fwd[waves cap {cap}] {tf:7.1f} us ({fl / tf / 1e6:6.1f} TF)")

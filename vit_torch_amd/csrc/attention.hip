@@ -277,6 +277,119 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16* __restrict__ 
   }
 }
 
+
+// ------------------------------------ forward, whole sequence in one CU ---
+// N <= 256: K and V of one (image, head) are staged ONCE (one batch of unconditional loads,
+// one barrier) for all nw = ceil(N/32) waves of the workgroup; each wave then walks the key
+// blocks with no further barrier.  Two such workgroups fit a CU (75 KB LDS, <= 128 VGPRs),
+// so one's staging burst runs under the other's softmax.
+template <int HD>
+__global__ __launch_bounds__(512) void attn_fwd_whole_kernel(const bf16* __restrict__ qkv,
+                                                             bf16* __restrict__ out,
+                                                             float* __restrict__ lse, int N, int H,
+                                                             float scale_log2e) {
+  using C = AttnCfg<HD>;
+  constexpr int CPR = HD / 8, IT = CPR / 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
+  const int NP = nw * 32;
+  char* Kl = smem;
+  char* Vl = smem + NP * C::KS;
+  const int lr = lane & 31, h5 = lane >> 5;
+  const int bh = blockIdx.x, b = bh / H, h = bh % H;
+  const int64_t ts = (int64_t)3 * H * HD;
+  const bf16* qb = qkv + (int64_t)b * N * ts + h * HD;
+  const bf16* kb_ = qb + H * HD;
+  const bf16* vb = qb + 2 * H * HD;
+  const int q0 = w * 32;
+  const int qrow = min(q0 + lr, N - 1);
+
+  bf16x8 qf[C::KSTEPS];
+#pragma unroll
+  for (int s = 0; s < C::KSTEPS; ++s)
+    qf[s] = *reinterpret_cast<const bf16x8*>(qb + (int64_t)qrow * ts + 16 * s + 8 * h5);
+  {
+    // NP*CPR 16-B pieces over nthr = NP*2 threads: CPR/2 per thread and matrix
+    bf16x8 k8[IT], v8[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = tid + i * nthr, row = min(c / CPR, N - 1), pc = c % CPR;
+      k8[i] = *reinterpret_cast<const bf16x8*>(kb_ + (int64_t)row * ts + pc * 8);
+      v8[i] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)row * ts + pc * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = tid + i * nthr, row = c / CPR, pc = c % CPR;
+      if (row >= N) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { k8[i][e] = (bf16)0.f; v8[i][e] = (bf16)0.f; }
+      }
+      *reinterpret_cast<bf16x8*>(Kl + row * C::KS + pc * 16) = k8[i];
+      *reinterpret_cast<bf16x8*>(Vl + row * C::VS + pc * 16) = v8[i];
+    }
+  }
+  __syncthreads();
+
+  f32x16 o[C::DB];
+#pragma unroll
+  for (int db = 0; db < C::DB; ++db) zero16(o[db]);
+  float m = -INFINITY, l = 0.f;
+  const int nsb = (N + 31) >> 5;
+#pragma unroll 1
+  for (int sb = 0; sb < nsb; ++sb) {
+    f32x16 s;
+    zero16(s);
+#pragma unroll
+    for (int ks = 0; ks < C::KSTEPS; ++ks) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(Kl + (sb * 32 + lr) * C::KS + (16 * ks + 8 * h5) * 2);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s, 0, 0, 0);
+    }
+    const int key0 = sb * 32;
+    if (key0 + 32 > N) {                       // ragged block only: mask keys >= N
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (key0 + mfma32_row(r, h5) >= N) s[r] = -INFINITY;
+    }
+    float tmax = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+#pragma unroll
+    for (int r = 4; r < 16; r += 2) tmax = fmaxf(tmax, fmaxf(s[r], s[r + 1]));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m, tmax * scale_log2e);
+    if (!__all(m_new == m)) {                  // some row's max moved: rescale once
+      const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+      l *= alpha;
+#pragma unroll
+      for (int db = 0; db < C::DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+      m = m_new;
+    }
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -m));
+      s[r] = p;
+      psum += p;
+    }
+    l += psum + __shfl_xor(psum, 32);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const bf16x8 pf = pack8(s, 8 * s2);
+#pragma unroll
+      for (int db = 0; db < C::DB; ++db) {
+        const bf16x8 a = load_tr_frag(Vl, C::VS, sb * 32 + 16 * s2, db * 32, lane);
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf, o[db], 0, 0, 0);
+      }
+    }
+  }
+  const int q = q0 + lr;
+  if (q < N) {
+    store_T_tile<HD>(out + ((int64_t)(b * (int64_t)N + q) * H + h) * HD, o, 1.f / l, h5);
+    if (h5 == 0) lse[(int64_t)bh * N + q] = (m + log2f(l)) * LN2;
+  }
+}
+
 // ------------------------------------------------------ backward: delta ---
 // delta[b,h,n] = sum_d dout[b,n,h,d] * out[b,n,h,d]
 template <int HD>
@@ -839,6 +952,29 @@ extern "C" int vitmi_attn_fwd(const void* qkv, void* out, float* lse, int dtype,
   int rc = check_attn(qkv, dtype, B, N, H, hd, "attn_fwd");
   if (rc) return rc;
   VITMI_REQUIRE(is_aligned(out, 8), VITMI_E_ALIGN, "attn_fwd: out must be 8-B aligned");
+  if (N <= 256 && g_attn_fwd_waves <= 0) {          // whole sequence resident: one workgroup per (image, head)
+    const int nwh = attn_waves(N);
+    const size_t ldsw = (size_t)nwh * 32 * (hd == 64 ? (AttnCfg<64>::KS + AttnCfg<64>::VS) : (AttnCfg<32>::KS + AttnCfg<32>::VS));
+    static bool attr64 = false, attr32 = false;
+    if (hd == 64) {
+      auto kern = attn_fwd_whole_kernel<64>;
+      if (!attr64) {
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (err != hipSuccess) return vitmi_fail((int)err, "attn_fwd: cannot raise dynamic LDS: %s", hipGetErrorString(err));
+        attr64 = true;
+      }
+      hipLaunchKernelGGL(kern, dim3((unsigned)(B * H)), dim3(64 * nwh), ldsw, stream, (const bf16*)qkv, (bf16*)out, lse, (int)N, (int)H, scale * LOG2E);
+    } else {
+      auto kern = attn_fwd_whole_kernel<32>;
+      if (!attr32) {
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (err != hipSuccess) return vitmi_fail((int)err, "attn_fwd: cannot raise dynamic LDS: %s", hipGetErrorString(err));
+        attr32 = true;
+      }
+      hipLaunchKernelGGL(kern, dim3((unsigned)(B * H)), dim3(64 * nwh), ldsw, stream, (const bf16*)qkv, (bf16*)out, lse, (int)N, (int)H, scale * LOG2E);
+    }
+    return vitmi_check_launch("attn_fwd_whole_kernel");
+  }
   // 4-wave workgroups (128 queries): three of them fit a CU (registers), so the K/V staging
   // of one overlaps the softmax of the others; measured 9 % faster than one 7-wave
   // workgroup per (image, head) at N = 197 although K/V are then staged twice
