@@ -214,13 +214,18 @@ def main():
         traffic = None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            traffic = pm["gemm_fast_kernel"]["hbm_bytes_per_launch"]
+            k = pm["gemm_fast_kernel"]
+            steps_prof = (pm.get("_meta") or {}).get("steps_profiled")
+            if steps_prof:      # one GEMM call may be several launches (split tail, split-K): per call
+                traffic = round(k["hbm_bytes_per_launch"] * k["launches"] / steps_prof / n_launch)
+            else:
+                traffic = k["hbm_bytes_per_launch"]
         except Exception:
             pass
         roof = {"bound": "mfma", "kernel": "gemm_fast_kernel (all GEMM launches of one step)",
                 "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                "traffic_note": "bytes/launch, rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE of this command (profiles/r01_pmc_traffic.json)",
+                "traffic_note": "HBM bytes per GEMM call (all gemm_fast_kernel launches of a step / calls), rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE of this command (profiles/r01_pmc_traffic.json)",
                 "flop_per_launch": round(tot_f / n_launch),
                 "launches_per_step": n_launch, "avg_launch_ms": round(tot_t / n_launch * 1e3, 4),
                 "gemm_ms_per_step": round(tot_t * 1e3, 3),

@@ -31,5 +31,9 @@ for k in sorted(fetch, key=lambda k: -(2 * fetch[k] + write.get(k, 0))):
     out[k] = {"launches": n, "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
               "hbm_bytes_per_launch": round(rd + wr)}
     print(f"{k[:60]:60s} n={n:5d}  read {rd/1e6:9.1f} MB  write {wr/1e6:9.1f} MB per launch")
+# steps profiled = launches of the once-per-step optimizer kernel (lets a reader turn
+# per-launch bytes into per-step bytes when one GEMM call is several launches)
+steps = [v["launches"] for k, v in out.items() if k.startswith("sgd_momentum_kernel")]
+out["_meta"] = {"steps_profiled": steps[0] if steps else None}
 if len(sys.argv) > 3:
     json.dump(out, open(sys.argv[3], "w"), indent=1)
