@@ -17,36 +17,110 @@ constexpr int TH_MAXC = 4;     // columns per lane -> row length <= 256
 
 template <typename T> __device__ __forceinline__ float ldf(const T* p) { return to_f32(*p); }
 
+// A lane owns TH_MAXC keys of a score row.  VEC: keys 4*lane .. 4*lane+3 (one 8/16-byte
+// access per head and tensor; needs ld % 4 == 0 and 4-element aligned bases) — otherwise
+// keys lane, lane+64, ... by element.  2-byte accesses made these kernels texture-address
+// bound (~10x their arithmetic); the vector form is what the engine uses.
+// The H x H mixing weights as wave-uniform values WITHOUT a memory access per use: lane k of
+// one VGPR holds W[k] (H*H <= 64) and v_readlane brings an entry into a scalar register.
+// (Indexing the global array inside the unrolled FMA nests put a scalar load and its wait in
+// front of every FMA: the backward kernel ran at ~1/10 of its arithmetic.)
+__device__ __forceinline__ float th_wlane(float v, int idx) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), idx));
+}
+#define TH_LOAD_W(dst, src_vgpr, H_)                                                    \
+  float dst[TH_MAXH][TH_MAXH];                                                          \
+  _Pragma("unroll") for (int a_ = 0; a_ < TH_MAXH; ++a_)                                \
+    _Pragma("unroll") for (int c_ = 0; c_ < TH_MAXH; ++c_)                              \
+      dst[a_][c_] = (a_ < (H_) && c_ < (H_)) ? th_wlane(src_vgpr, a_ * (H_) + c_) : 0.f
+
+template <bool VEC> __device__ __forceinline__ int th_key(int lane, int c) { return VEC ? lane * 4 + c : c * 64 + lane; }
+
+template <typename T> struct Keep4;                 // 4 keys of one head, compact in registers
+template <> struct Keep4<bf16> {
+  bf16x4 v;
+  __device__ __forceinline__ float get(int c) const { return (float)v[c]; }
+  __device__ __forceinline__ void set(int c, float x) { v[c] = (bf16)x; }
+};
+template <> struct Keep4<float> {
+  f32x4 v;
+  __device__ __forceinline__ float get(int c) const { return v[c]; }
+  __device__ __forceinline__ void set(int c, float x) { v[c] = x; }
+};
+template <typename T, bool VEC>
+__device__ __forceinline__ Keep4<T> th_load(const T* row, int lane, int Nk, bool head_ok) {
+  Keep4<T> k;
+  if constexpr (VEC) {
+    // UNCONDITIONAL load from a clamped position, zeroed by selects afterwards: a branch
+    // around a load makes hipcc wait for every load separately (48 HBM round trips per score
+    // row; the caller already clamps the head index)
+    const int lc = min(lane * 4, (Nk - 1) / 4 * 4);
+    if constexpr (sizeof(T) == 2) k.v = *reinterpret_cast<const bf16x4*>(row + lc);
+    else k.v = *reinterpret_cast<const f32x4*>(row + lc);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (!head_ok || lane * 4 + c >= Nk) k.set(c, 0.f);     // pad columns may hold anything
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) k.set(c, 0.f);
+    if (!head_ok) return k;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c * 64 + lane < Nk) k.set(c, to_f32(row[c * 64 + lane]));
+  }
+  return k;
+}
+template <typename T, bool VEC>
+__device__ __forceinline__ void th_store(T* row, int lane, int Nk, const Keep4<T>& k) {
+  if constexpr (VEC) {
+    if (lane * 4 < Nk) {                            // pad columns inside the vector get zeros
+      Keep4<T> o = k;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (lane * 4 + c >= Nk) o.set(c, 0.f);
+      if constexpr (sizeof(T) == 2) *reinterpret_cast<bf16x4*>(row + lane * 4) = o.v;
+      else *reinterpret_cast<f32x4*>(row + lane * 4) = o.v;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c * 64 + lane < Nk) row[c * 64 + lane] = from_f32<T>(k.get(c));
+  }
+}
+
 // ---- forward: S[B,H,N,ld] -> P (softmax of mixed scores), Pm (mixed probabilities)
-template <typename T>
+template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void th_softmax_fwd_kernel(const T* __restrict__ S, const float* __restrict__ Wl,
                                                             const float* __restrict__ bl, const float* __restrict__ Ww,
                                                             const float* __restrict__ bw, T* __restrict__ P,
                                                             T* __restrict__ Pm, int64_t rows /*B*N*/, int H, int N,
                                                             int Nk, int ld) {
+  static_assert(TH_MAXC == 4, "a lane owns four keys");
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * 4 + w;
   if (row >= rows) return;
   const int64_t b = row / N, i = row % N;
+  const float wl_v = lane < H * H ? Wl[lane] : 0.f, ww_v = lane < H * H ? Ww[lane] : 0.f;
+  const float bl_v = lane < H ? bl[lane] : 0.f, bw_v = lane < H ? bw[lane] : 0.f;
   float s[TH_MAXH][TH_MAXC], p[TH_MAXH][TH_MAXC];
 #pragma unroll
-  for (int h = 0; h < TH_MAXH; ++h)
+  for (int h = 0; h < TH_MAXH; ++h) {
+    const Keep4<T> k = th_load<T, VEC>(S + ((b * H + (h < H ? h : 0)) * N + i) * ld, lane, Nk, h < H);
 #pragma unroll
-    for (int c = 0; c < TH_MAXC; ++c) {
-      const int j = c * 64 + lane;
-      s[h][c] = (h < H && j < Nk) ? ldf(S + ((b * H + h) * N + i) * ld + j) : 0.f;
-    }
+    for (int c = 0; c < TH_MAXC; ++c) s[h][c] = k.get(c);
+  }
+  TH_LOAD_W(wl, wl_v, H);
 #pragma unroll
   for (int hp = 0; hp < TH_MAXH; ++hp) {
     if (hp >= H) break;
+    const float blh = th_wlane(bl_v, hp);
     float v[TH_MAXC], mx = -INFINITY;
 #pragma unroll
     for (int c = 0; c < TH_MAXC; ++c) {
-      float a = bl[hp];
+      float a = blh;
 #pragma unroll
-      for (int h = 0; h < TH_MAXH; ++h)
-        if (h < H) a = fmaf(Wl[hp * H + h], s[h][c], a);
-      v[c] = (c * 64 + lane < Nk) ? a : -INFINITY;
+      for (int h = 0; h < TH_MAXH; ++h) a = fmaf(wl[hp][h], s[h][c], a);
+      v[c] = (th_key<VEC>(lane, c) < Nk) ? a : -INFINITY;
       mx = fmaxf(mx, v[c]);
     }
     mx = wave_max(mx);
@@ -55,38 +129,48 @@ __global__ __launch_bounds__(256) void th_softmax_fwd_kernel(const T* __restrict
     for (int c = 0; c < TH_MAXC; ++c) { v[c] = expf(v[c] - mx); sum += v[c]; }
     sum = wave_sum(sum);
     const float inv = 1.f / sum;
+    Keep4<T> o;
 #pragma unroll
     for (int c = 0; c < TH_MAXC; ++c) {
-      // backward differentiates at the STORED probabilities
-      p[hp][c] = to_f32(from_f32<T>(v[c] * inv));
-      const int j = c * 64 + lane;
-      if (j < Nk) P[((b * H + hp) * N + i) * ld + j] = from_f32<T>(p[hp][c]);
+      o.set(c, v[c] * inv);
+      p[hp][c] = o.get(c);                          // backward differentiates at the STORED probabilities
+    }
+    th_store<T, VEC>(P + ((b * H + hp) * N + i) * ld, lane, Nk, o);
+  }
+  TH_LOAD_W(ww, ww_v, H);
+#pragma unroll
+  for (int hp = 0; hp < TH_MAXH; ++hp) {            // heads >= H: p was never written
+    if (hp >= H) {
+#pragma unroll
+      for (int c = 0; c < TH_MAXC; ++c) p[hp][c] = 0.f;
     }
   }
 #pragma unroll
   for (int ho = 0; ho < TH_MAXH; ++ho) {
     if (ho >= H) break;
+    const float bwh = th_wlane(bw_v, ho);
+    Keep4<T> o;
 #pragma unroll
     for (int c = 0; c < TH_MAXC; ++c) {
-      float a = bw[ho];
+      float a = bwh;
 #pragma unroll
-      for (int hp = 0; hp < TH_MAXH; ++hp)
-        if (hp < H) a = fmaf(Ww[ho * H + hp], p[hp][c], a);
-      const int j = c * 64 + lane;
-      if (j < Nk) Pm[((b * H + ho) * N + i) * ld + j] = from_f32<T>(a);
+      for (int hp = 0; hp < TH_MAXH; ++hp) a = fmaf(ww[ho][hp], p[hp][c], a);
+      o.set(c, a);
     }
+    th_store<T, VEC>(Pm + ((b * H + ho) * N + i) * ld, lane, Nk, o);
   }
 }
 
 // ---- backward.  Per-lane accumulators of the four parameter gradients; part layout per
 // wave: [dWl H*H | dbl H | dWw H*H | dbw H] (2*H*H + 2*H floats)
-template <typename T>
+template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const T* __restrict__ S, const T* __restrict__ P,
                                                             const T* __restrict__ dPm, const float* __restrict__ Wl,
                                                             const float* __restrict__ Ww, T* __restrict__ dS,
                                                             float* __restrict__ part, int64_t rows, int H, int N,
                                                             int Nk, int ld) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float wl_v = lane < H * H ? Wl[lane] : 0.f, ww_v = lane < H * H ? Ww[lane] : 0.f;
   float aWl[TH_MAXH][TH_MAXH], aWw[TH_MAXH][TH_MAXH], abl[TH_MAXH], abw[TH_MAXH];
 #pragma unroll
   for (int a = 0; a < TH_MAXH; ++a) {
@@ -94,97 +178,142 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const T* __restrict
 #pragma unroll
     for (int c = 0; c < TH_MAXH; ++c) { aWl[a][c] = 0.f; aWw[a][c] = 0.f; }
   }
-  // Two passes per row, one 64-key chunk at a time (the whole row of S, P, dP' for 8 heads
-  // is 96 values per lane: holding it beside the 144 gradient accumulators leaves one wave
-  // per SIMD).  Pass 1: dP = Ww^T dP', the softmax row dots, dWw / dbw.  Pass 2 re-reads P
-  // (L2) and S: dS' = P (dP - dot), dS = Wl^T dS', dWl / dbl.  dP of all chunks stays in
-  // registers between the passes.
+  // Two passes per row with the row kept COMPACT (Keep4: the 96 values of S, P, dP' for 8
+  // heads would otherwise push the 144 gradient accumulators out of the register file).
+  // Pass 1: dP = Ww^T dP', the softmax row dots, dWw / dbw.  Pass 2 re-reads P (L2) and S:
+  // dS' = P (dP - dot), dS = Wl^T dS', dWl / dbl.  dP stays in registers between the passes.
   for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < rows; row += (int64_t)gridDim.x * 4) {
     const int64_t b = row / N, i = row % N;
     float dp[TH_MAXH][TH_MAXC], dot[TH_MAXH];
 #pragma unroll
     for (int hp = 0; hp < TH_MAXH; ++hp) dot[hp] = 0.f;
-#pragma unroll
-    for (int c = 0; c < TH_MAXC; ++c) {
-      const int j = c * 64 + lane;
-      if (c * 64 >= Nk) {                          // wave-uniform: chunk beyond the row
-#pragma unroll
-        for (int hp = 0; hp < TH_MAXH; ++hp) dp[hp][c] = 0.f;
-        continue;
-      }
-      float p[TH_MAXH], g[TH_MAXH];
+    {
+      Keep4<T> pk[TH_MAXH], gk[TH_MAXH];
 #pragma unroll
       for (int h = 0; h < TH_MAXH; ++h) {
-        const bool ok = h < H && j < Nk;
-        const int64_t o = ((b * H + h) * N + i) * ld + j;
-        p[h] = ok ? ldf(P + o) : 0.f;
-        g[h] = ok ? ldf(dPm + o) : 0.f;            // dL/dP'
+        const int64_t o = ((b * H + (h < H ? h : 0)) * N + i) * ld;
+        pk[h] = th_load<T, VEC>(P + o, lane, Nk, h < H);
+        gk[h] = th_load<T, VEC>(dPm + o, lane, Nk, h < H);      // dL/dP'
       }
-      // through proj_w: dP[hp] = sum_ho Ww[ho][hp] dP'[ho];  dWw[ho][hp] += dP'[ho] * P[hp]
+      TH_LOAD_W(ww, ww_v, H);
 #pragma unroll
-      for (int hp = 0; hp < TH_MAXH; ++hp) {
-        float a = 0.f;
+      for (int c = 0; c < TH_MAXC; ++c) {
+        float p[TH_MAXH], g[TH_MAXH];
 #pragma unroll
-        for (int ho = 0; ho < TH_MAXH; ++ho)
-          if (ho < H && hp < H) a = fmaf(Ww[ho * H + hp], g[ho], a);
-        dp[hp][c] = a;
-        dot[hp] = fmaf(a, p[hp], dot[hp]);
-      }
+        for (int h = 0; h < TH_MAXH; ++h) { p[h] = pk[h].get(c); g[h] = gk[h].get(c); }
+        // through proj_w: dP[hp] = sum_ho Ww[ho][hp] dP'[ho];  dWw[ho][hp] += dP'[ho] * P[hp]
 #pragma unroll
-      for (int ho = 0; ho < TH_MAXH; ++ho) {
-        abw[ho] += g[ho];
+        for (int hp = 0; hp < TH_MAXH; ++hp) {
+          float a = 0.f;
 #pragma unroll
-        for (int hp = 0; hp < TH_MAXH; ++hp) aWw[ho][hp] = fmaf(g[ho], p[hp], aWw[ho][hp]);
+          for (int ho = 0; ho < TH_MAXH; ++ho) a = fmaf(ww[ho][hp], g[ho], a);
+          dp[hp][c] = a;
+          dot[hp] = fmaf(a, p[hp], dot[hp]);
+        }
+#pragma unroll
+        for (int ho = 0; ho < TH_MAXH; ++ho) {
+          abw[ho] += g[ho];
+#pragma unroll
+          for (int hp = 0; hp < TH_MAXH; ++hp) aWw[ho][hp] = fmaf(g[ho], p[hp], aWw[ho][hp]);
+        }
       }
     }
 #pragma unroll
     for (int hp = 0; hp < TH_MAXH; ++hp) dot[hp] = wave_sum(dot[hp]);
-#pragma unroll
-    for (int c = 0; c < TH_MAXC; ++c) {
-      const int j = c * 64 + lane;
-      if (c * 64 >= Nk) continue;
-      float p[TH_MAXH], sv[TH_MAXH], ds[TH_MAXH];
+    {
+      Keep4<T> pk[TH_MAXH], sk[TH_MAXH], ok[TH_MAXH];
 #pragma unroll
       for (int h = 0; h < TH_MAXH; ++h) {
-        const bool ok = h < H && j < Nk;
-        const int64_t o = ((b * H + h) * N + i) * ld + j;
-        p[h] = ok ? ldf(P + o) : 0.f;
-        sv[h] = ok ? ldf(S + o) : 0.f;
+        const int64_t o = ((b * H + (h < H ? h : 0)) * N + i) * ld;
+        pk[h] = th_load<T, VEC>(P + o, lane, Nk, h < H);
+        sk[h] = th_load<T, VEC>(S + o, lane, Nk, h < H);
       }
-      // through the softmax: dS'[hp] = P[hp] * (dP[hp] - sum_j dP[hp] P[hp])
+      TH_LOAD_W(wl, wl_v, H);
 #pragma unroll
-      for (int hp = 0; hp < TH_MAXH; ++hp) ds[hp] = p[hp] * (dp[hp][c] - dot[hp]);
-      // through proj_l: dS[h] = sum_hp Wl[hp][h] dS'[hp];  dWl[hp][h] += dS'[hp] * S[h]
+      for (int c = 0; c < TH_MAXC; ++c) {
+        float sv[TH_MAXH], ds[TH_MAXH];
+        // through the softmax: dS'[hp] = P[hp] * (dP[hp] - sum_j dP[hp] P[hp])
 #pragma unroll
-      for (int hp = 0; hp < TH_MAXH; ++hp) {
-        abl[hp] += ds[hp];
+        for (int hp = 0; hp < TH_MAXH; ++hp) {
+          ds[hp] = pk[hp].get(c) * (dp[hp][c] - dot[hp]);
+          sv[hp] = sk[hp].get(c);
+        }
+        // through proj_l: dS[h] = sum_hp Wl[hp][h] dS'[hp];  dWl[hp][h] += dS'[hp] * S[h]
 #pragma unroll
-        for (int h = 0; h < TH_MAXH; ++h) aWl[hp][h] = fmaf(ds[hp], sv[h], aWl[hp][h]);
+        for (int hp = 0; hp < TH_MAXH; ++hp) {
+          abl[hp] += ds[hp];
+#pragma unroll
+          for (int h = 0; h < TH_MAXH; ++h) aWl[hp][h] = fmaf(ds[hp], sv[h], aWl[hp][h]);
+        }
+#pragma unroll
+        for (int h = 0; h < TH_MAXH; ++h) {
+          float a = 0.f;
+#pragma unroll
+          for (int hp = 0; hp < TH_MAXH; ++hp) a = fmaf(wl[hp][h], ds[hp], a);
+          ok[h].set(c, a);
+        }
       }
 #pragma unroll
-      for (int h = 0; h < TH_MAXH; ++h) {
-        if (h >= H) break;
-        float a = 0.f;
-#pragma unroll
-        for (int hp = 0; hp < TH_MAXH; ++hp)
-          if (hp < H) a = fmaf(Wl[hp * H + h], ds[hp], a);
-        if (j < Nk) dS[((b * H + h) * N + i) * ld + j] = from_f32<T>(a);
-      }
+      for (int h = 0; h < TH_MAXH; ++h)
+        if (h < H) th_store<T, VEC>(dS + ((b * H + h) * N + i) * ld, lane, Nk, ok[h]);
     }
+  }
+  // ---- 144 per-lane accumulators -> one partial row per wave.  A plain wave_sum per value
+  // is 6 dependent shuffles each (864 ds_bpermute, ~45 us per wave: more than the rows
+  // themselves); the transposing butterfly halves the value count at each of the first four
+  // lane bits (72 + 36 + 18 + 9 shuffles), then two plain steps fold the last 9 values.
+  constexpr int NV = 2 * TH_MAXH * TH_MAXH + 2 * TH_MAXH;     // 144, padded layout
+  float v[NV];
+#pragma unroll
+  for (int a = 0; a < TH_MAXH; ++a) {
+#pragma unroll
+    for (int c = 0; c < TH_MAXH; ++c) {
+      v[a * TH_MAXH + c] = aWl[a][c];
+      v[TH_MAXH * TH_MAXH + TH_MAXH + a * TH_MAXH + c] = aWw[a][c];
+    }
+    v[TH_MAXH * TH_MAXH + a] = abl[a];
+    v[2 * TH_MAXH * TH_MAXH + TH_MAXH + a] = abw[a];
+  }
+  int base = 0;
+#pragma unroll
+  for (int sbit = 0; sbit < 4; ++sbit) {
+    const int cnt = NV >> (sbit + 1);                // 72, 36, 18, 9
+    const bool up = (lane >> sbit) & 1;
+#pragma unroll
+    for (int k = 0; k < cnt; ++k) {
+      float lo = v[k], hi = v[k + cnt];
+      asm volatile("" : "+v"(lo), "+v"(hi));         // keep the selects from becoming a dynamic index
+      const float keep = up ? hi : lo, send = up ? lo : hi;
+      v[k] = keep + __shfl_xor(send, 1 << sbit, 64);
+    }
+    base += up ? cnt : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    v[k] += __shfl_xor(v[k], 16, 64);
+    v[k] += __shfl_xor(v[k], 32, 64);
   }
   const int stride = 2 * H * H + 2 * H;
   float* prow = part + ((int64_t)blockIdx.x * 4 + w) * stride;
+  if (lane < 16) {
 #pragma unroll
-  for (int a = 0; a < TH_MAXH; ++a) {
-    if (a >= H) break;
-#pragma unroll
-    for (int c = 0; c < TH_MAXH; ++c) {
-      if (c >= H) break;
-      const float x = wave_sum(aWl[a][c]), y = wave_sum(aWw[a][c]);
-      if (lane == 0) { prow[a * H + c] = x; prow[H * H + H + a * H + c] = y; }
+    for (int k = 0; k < 9; ++k) {
+      const int idx = base + k;                      // index in the padded layout
+      constexpr int HH = TH_MAXH * TH_MAXH;
+      if (idx < HH) {
+        const int a = idx / TH_MAXH, c = idx % TH_MAXH;
+        if (a < H && c < H) prow[a * H + c] = v[k];
+      } else if (idx < HH + TH_MAXH) {
+        const int a = idx - HH;
+        if (a < H) prow[H * H + a] = v[k];
+      } else if (idx < 2 * HH + TH_MAXH) {
+        const int a = (idx - HH - TH_MAXH) / TH_MAXH, c = (idx - HH - TH_MAXH) % TH_MAXH;
+        if (a < H && c < H) prow[H * H + H + a * H + c] = v[k];
+      } else {
+        const int a = idx - 2 * HH - TH_MAXH;
+        if (a < H) prow[2 * H * H + H + a] = v[k];
+      }
     }
-    const float x = wave_sum(abl[a]), y = wave_sum(abw[a]);
-    if (lane == 0) { prow[H * H + a] = x; prow[2 * H * H + H + a] = y; }
   }
 }
 
@@ -346,11 +475,14 @@ extern "C" int vitmi_th_softmax_fwd(const void* S, const float* Wl, const float*
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   const int64_t rows = B * N;
   dim3 grid((unsigned)((rows + 3) / 4));
-  if (dtype == VITMI_BF16)
-    hipLaunchKernelGGL((th_softmax_fwd_kernel<bf16>), grid, dim3(256), 0, stream, (const bf16*)S, Wl, bl, Ww, bw, (bf16*)P, (bf16*)Pm, rows, (int)H, (int)N, (int)Nk, (int)ld);
-  else if (dtype == VITMI_F32)
-    hipLaunchKernelGGL((th_softmax_fwd_kernel<float>), grid, dim3(256), 0, stream, (const float*)S, Wl, bl, Ww, bw, (float*)P, (float*)Pm, rows, (int)H, (int)N, (int)Nk, (int)ld);
+  // four keys per lane as one vector when the rows allow it
+  const size_t va = dtype == VITMI_BF16 ? 8 : 16;
+  const bool vec = ld % 4 == 0 && ld >= (Nk + 3) / 4 * 4 && is_aligned(S, va) && is_aligned(P, va) && is_aligned(Pm, va);
+#define TH_FWD(T, V) hipLaunchKernelGGL((th_softmax_fwd_kernel<T, V>), grid, dim3(256), 0, stream, (const T*)S, Wl, bl, Ww, bw, (T*)P, (T*)Pm, rows, (int)H, (int)N, (int)Nk, (int)ld)
+  if (dtype == VITMI_BF16) { if (vec) TH_FWD(bf16, true); else TH_FWD(bf16, false); }
+  else if (dtype == VITMI_F32) { if (vec) TH_FWD(float, true); else TH_FWD(float, false); }
   else return vitmi_fail(VITMI_E_DTYPE, "th_softmax_fwd: bad dtype");
+#undef TH_FWD
   return vitmi_check_launch("th_softmax_fwd_kernel");
 }
 
@@ -370,11 +502,13 @@ extern "C" int vitmi_th_softmax_bwd(const void* S, const void* P, const void* dP
   const int64_t rows = B * N;
   const int nblk = th_bwd_blocks(rows);
   float* part = reinterpret_cast<float*>(workspace);
-  if (dtype == VITMI_BF16)
-    hipLaunchKernelGGL((th_softmax_bwd_kernel<bf16>), dim3(nblk), dim3(256), 0, stream, (const bf16*)S, (const bf16*)P, (const bf16*)dPm, Wl, Ww, (bf16*)dS, part, rows, (int)H, (int)N, (int)Nk, (int)ld);
-  else if (dtype == VITMI_F32)
-    hipLaunchKernelGGL((th_softmax_bwd_kernel<float>), dim3(nblk), dim3(256), 0, stream, (const float*)S, (const float*)P, (const float*)dPm, Wl, Ww, (float*)dS, part, rows, (int)H, (int)N, (int)Nk, (int)ld);
+  const size_t va = dtype == VITMI_BF16 ? 8 : 16;
+  const bool vec = ld % 4 == 0 && ld >= (Nk + 3) / 4 * 4 && is_aligned(S, va) && is_aligned(P, va) && is_aligned(dPm, va) && is_aligned(dS, va);
+#define TH_BWD(T, V) hipLaunchKernelGGL((th_softmax_bwd_kernel<T, V>), dim3(nblk), dim3(256), 0, stream, (const T*)S, (const T*)P, (const T*)dPm, Wl, Ww, (T*)dS, part, rows, (int)H, (int)N, (int)Nk, (int)ld)
+  if (dtype == VITMI_BF16) { if (vec) TH_BWD(bf16, true); else TH_BWD(bf16, false); }
+  else if (dtype == VITMI_F32) { if (vec) TH_BWD(float, true); else TH_BWD(float, false); }
   else return vitmi_fail(VITMI_E_DTYPE, "th_softmax_bwd: bad dtype");
+#undef TH_BWD
   rc = vitmi_check_launch("th_softmax_bwd_kernel");
   if (rc) return rc;
   const int64_t stride = 2 * H * H + 2 * H;
