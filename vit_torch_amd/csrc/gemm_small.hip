@@ -72,10 +72,14 @@ __device__ __forceinline__ int y_pitch(int N) { return N * 2 + (((N * 2) % 128 =
 __device__ __forceinline__ void stage_rows(char* img, int RS, const bf16* X, int64_t ld, int r0, int rows,
                                            int R_total, int cols, int cols_pad, int tid, int nthr) {
   const int cpr = cols_pad / 8;                    // 16-B pieces per staged row
+  const int last_pc = (cols - 1) / 8 * 8;
   for (int c = tid; c < rows * cpr; c += nthr) {
     const int r = c / cpr, pc = (c % cpr) * 8;
-    bf16x8 v = zero8();
-    if (r0 + r < R_total && pc < cols) v = *reinterpret_cast<const bf16x8*>(X + (int64_t)(r0 + r) * ld + pc);
+    // unconditional load from a clamped position, zeroed afterwards (a branch around the
+    // load would make every piece wait for its own round trip)
+    const bool ok = r0 + r < R_total && pc < cols;
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(X + (int64_t)min(r0 + r, R_total - 1) * ld + min(pc, last_pc));
+    if (!ok) v = zero8();
     *reinterpret_cast<bf16x8*>(img + r * RS + pc * 2) = v;
   }
 }

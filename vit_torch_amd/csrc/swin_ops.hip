@@ -104,14 +104,20 @@ __device__ __forceinline__ bf16x8 win_row_frag(const bf16* base, int64_t ts, con
 // stage [64 rows][32] bf16 of one head into a wave-private LDS image (rows >= N zero)
 __device__ __forceinline__ void win_stage(char* img, const bf16* base, int64_t ts, const WinGeom& geo, int64_t bw,
                                           int N, int lane) {
+  bf16x8 v[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {                    // unconditional loads from clamped rows (a branch
+    const int p = lane + 64 * t, row = min(p >> 2, N - 1), c = p & 3;   // around a load serialises them)
+    v[t] = *reinterpret_cast<const bf16x8*>(base + win_token(geo, bw, row) * ts + 8 * c);
+  }
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int p = lane + 64 * t, row = p >> 2, c = p & 3;
-    bf16x8 v;
+    if (row >= N) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
-    if (row < N) v = *reinterpret_cast<const bf16x8*>(base + win_token(geo, bw, row) * ts + 8 * c);
-    *reinterpret_cast<bf16x8*>(img + row * WP + c * 16) = v;
+      for (int e = 0; e < 8; ++e) v[t][e] = (bf16)0.f;
+    }
+    *reinterpret_cast<bf16x8*>(img + row * WP + c * 16) = v[t];
   }
 }
 // A/B fragment whose k runs over the ROWS of a staged image, in the slot order
