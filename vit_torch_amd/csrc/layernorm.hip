@@ -24,13 +24,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, i
   const TX* xr = x + row * xs;
   f32x4 v[NV];
   float s = 0.f;
+  // loads are unconditional from a clamped column (a branch around a load makes hipcc
+  // drain vmcnt after each: one HBM round trip per chunk instead of one per row)
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = load4<TX>(xr + min((i * 64 + lane) * 4, D - 4));
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * 4;
-    if (c < D) {
-      v[i] = load4<TX>(xr + c);
-      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-    }
+    if (c < D) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
   }
   const float mean = wave_sum(s) / (float)D;
   float q = 0.f;
@@ -52,9 +53,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, i
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * 4;
+    const int cc = min(c, D - 4);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + cc);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(beta + cc);
     if (c < D) {
-      const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
       f32x4 o;
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
@@ -99,12 +101,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
     const TX* xr = x + row * xs;
     f32x4 xh[NV], dv[NV];
     float s1 = 0.f, s2 = 0.f;
+    // unconditional loads from clamped columns first (see ln_fwd_kernel)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int cc = min((i * 64 + lane) * 4, D - 4);
+      xh[i] = load4<TX>(xr + cc);
+      dv[i] = load4<TDY>(dyr + cc);
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 4;
       if (c < D) {
-        const f32x4 xv = load4<TX>(xr + c);
-        dv[i] = load4<TDY>(dyr + c);
+        const f32x4 xv = xh[i];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           xh[i][j] = (xv[j] - mu) * rs;
@@ -119,6 +127,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
     const float c1 = wave_sum(s1) * invD, c2 = wave_sum(s2) * invD;
     float rsc = 1.f;
     if (gb_rowscale) rsc = gb_rowscale[(uint32_t)row / (uint32_t)rpg];   // wave-uniform branch; M < 2^32
+    f32x4 gin[NV];
+    if (g_in) {                                    // wave-uniform; loads again unconditional
+#pragma unroll
+      for (int i = 0; i < NV; ++i) gin[i] = load4<TG>(g_in + row * gstride + min((i * 64 + lane) * 4, D - 4));
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 4;
@@ -127,9 +140,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = rs * (dv[i][j] - c1 - xh[i][j] * c2);
         if (g_in) {
-          const f32x4 gi = load4<TG>(g_in + row * gstride + c);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] += gi[j];
+          for (int j = 0; j < 4; ++j) o[j] += gin[i][j];
         }
         store4<TG>(g_out + row * gstride + c, o);
         // the GEMM-operand copy (and its column sum) carry the LayerScale of the branch
