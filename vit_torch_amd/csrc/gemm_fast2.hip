@@ -237,8 +237,9 @@ __global__ __launch_bounds__(NT2, 2) void gemm_fast2_kernel(GemmArgs g, int tile
   const int64_t ncol = n0 + wn * 64 + rc;
   const bool col_ok = ncol < g.N;                  // N % 8 == 0: a lane's W columns are all in or all out
   if constexpr (!SPLITK) {
-    if (g.e.bias && col_ok) loadv<float, W>(g.e.bias + ncol, bias_r);
-    if (MODE == VITMI_EPI_RESIDUAL && g.e.gamma && col_ok) loadv<float, W>(g.e.gamma + ncol, gamma_r);
+    const int64_t nc = col_ok ? ncol : g.N - W;
+    if (g.e.bias) loadv<float, W>(g.e.bias + nc, bias_r);
+    if (MODE == VITMI_EPI_RESIDUAL && g.e.gamma) loadv<float, W>(g.e.gamma + nc, gamma_r);
   }
   constexpr int NJ = 16 / RPI;                     // row groups per strip
   const bool side = !SPLITK && epi_has_side<MODE, TC>(g.e);
@@ -250,11 +251,14 @@ __global__ __launch_bounds__(NT2, 2) void gemm_fast2_kernel(GemmArgs g, int tile
   for (int j = 0; j < NJ; ++j)
 #pragma unroll
     for (int i = 0; i < W; ++i) { sx[0][j][i] = 0.f; sx[1][j][i] = 0.f; }
+  // side inputs are loaded UNCONDITIONALLY from clamped rows / columns (a per-lane branch
+  // around a load makes hipcc wait for each one); what a masked lane loads is never used
+  const int64_t ncol_c = col_ok ? ncol : g.N - W;
   if (side) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int64_t ms = m0 + wm * 128 + j * RPI + rr;
-      if (col_ok && ms < g.M) epi_side<MODE, TC, W>(g.e, ms, ncol, sx[0][j]);
+      epi_side<MODE, TC, W>(g.e, ms < g.M ? ms : g.M - 1, ncol_c, sx[0][j]);
     }
   }
 #pragma unroll
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_fast2_kernel(GemmArgs g, int tile
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int64_t ms = m0 + wm * 128 + (mi + 1) * 16 + j * RPI + rr;
-        if (col_ok && ms < g.M) epi_side<MODE, TC, W>(g.e, ms, ncol, sx[(mi + 1) & 1][j]);
+        epi_side<MODE, TC, W>(g.e, ms < g.M ? ms : g.M - 1, ncol_c, sx[(mi + 1) & 1][j]);
       }
     }
 #pragma unroll
