@@ -66,3 +66,73 @@ def test_bucketed_allreduce_overlapped_with_backward_matches_plain_step(nccl_wor
     assert len(red.launched) >= 3, "several buckets must have been exchanged during backward"
     assert l0 == l1, (l0, l1)
     assert torch.equal(p0, p1), "an all-reduce over one rank must not change the step"
+
+
+# ---- two ranks on ONE GPU over gloo: the real multi-rank logic (parameter broadcast, bucket
+# spans, SUM + grad_scale = mean) through the HIP engine and its two-stream backward.
+def _two_rank_worker(rank, world, port, compute, outdir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vit_torch_amd import CrossEntropyLoss, FusedSGD, VisionTransformer
+    from vit_torch_amd.ddp import GradReducer
+    torch.cuda.set_device(0)
+    torch.manual_seed(100 + rank)                     # deliberately different init per rank
+    m = VisionTransformer(img_size=64, patch_size=16, embed_dim=256, depth=3, num_heads=4, num_classes=10,
+                          compute_dtype=compute).cuda()
+    m.head = torch.nn.Linear(256, 10, bias=False).cuda()
+    eng = m.engine()
+    red = GradReducer(eng.pack, min_bucket_elems=1 << 18)
+    red.broadcast_parameters(0)                       # rank 0's weights everywhere
+    eng.reducer = red
+    opt = FusedSGD(m.parameters(), lr=1e-2, momentum=0.9, grad_scale=1.0 / world)
+    g = torch.Generator("cpu").manual_seed(0)
+    X = torch.randn(512, 3, 64, 64, generator=g)
+    Y = torch.randint(0, 10, (512,), generator=g)
+    xs, ys = X[rank * 256:(rank + 1) * 256].cuda(), Y[rank * 256:(rank + 1) * 256].cuda()
+    for _ in range(2):
+        opt.zero_grad()
+        loss = CrossEntropyLoss()(m(xs), ys)
+        loss.backward()
+        opt.step()
+    torch.cuda.synchronize()
+    # results through files: a tensor in an mp.Queue can be lost when the producer exits first
+    torch.save((eng.pack.flat.detach().cpu(), len(red.launched)), os.path.join(outdir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+def test_two_ranks_on_one_gpu_match_the_global_batch_step(lib, compute, tmp_path):
+    import torch.multiprocessing as mp
+    from vit_torch_amd import CrossEntropyLoss, FusedSGD, VisionTransformer
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, compute, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    got = [(r,) + tuple(torch.load(tmp_path / f"rank{r}.pt")) for r in range(2)]
+    assert torch.equal(got[0][1], got[1][1]), "ranks must hold identical parameters after the exchange"
+    assert got[0][2] >= 4, "several buckets per backward"
+    # single process, global batch of 512, same initial weights as rank 0
+    torch.manual_seed(100)
+    m = VisionTransformer(img_size=64, patch_size=16, embed_dim=256, depth=3, num_heads=4, num_classes=10,
+                          compute_dtype=compute).cuda()
+    m.head = torch.nn.Linear(256, 10, bias=False).cuda()
+    opt = FusedSGD(m.parameters(), lr=1e-2, momentum=0.9)
+    g = torch.Generator("cpu").manual_seed(0)
+    X = torch.randn(512, 3, 64, 64, generator=g).cuda()
+    Y = torch.randint(0, 10, (512,), generator=g).cuda()
+    for _ in range(2):
+        opt.zero_grad()
+        CrossEntropyLoss()(m(X), Y).backward()
+        opt.step()
+    want = m.engine().pack.flat.detach().cpu()
+    err = (got[0][1] - want).norm() / want.norm()
+    # mean of two half-batch means == global mean; fp32 differs only by summation order
+    assert err < (2e-6 if compute == "fp32" else 2e-4), err
