@@ -213,9 +213,12 @@ int vitmi_win_attn_fwd(const void* qkv, void* out, float* lse, const float* bias
                        int dtype, int64_t Bw, int64_t H, int64_t N, int64_t hd,
                        int64_t Himg, int64_t Wimg, int64_t ws, int64_t shift, float scale, void* stream);
 size_t vitmi_win_attn_bwd_workspace(int64_t Bw, int64_t H, int64_t N);
-/* dqkv (token order) and dbias [H,N,N] = sum over windows of d(score) (deterministic) */
+/* dqkv (token order) and dbias [H,N,N] = sum over windows of d(score) (deterministic).
+ * dqkv_bias (optional, fp32 [3*H*hd], overwritten): column sums of dqkv = the qkv Linear's bias
+ * gradient, without reading dqkv back; only where vitmi_win_attn_bwd_fuses_qkv_bias() is 1. */
+int vitmi_win_attn_bwd_fuses_qkv_bias(int dtype, int64_t hd);
 int vitmi_win_attn_bwd(const void* qkv, const void* dout, const float* lse, const float* bias,
-                       const float* mask, void* dqkv, float* dbias, int dtype,
+                       const float* mask, void* dqkv, float* dbias, float* dqkv_bias, int dtype,
                        int64_t Bw, int64_t H, int64_t N, int64_t hd,
                        int64_t Himg, int64_t Wimg, int64_t ws, int64_t shift, float scale,
                        void* workspace, size_t workspace_bytes, void* stream);

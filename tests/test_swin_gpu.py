@@ -64,6 +64,14 @@ def test_window_attention_in_token_order(ops, dt, B, Hh, Ww, ws, shift, H, hd):
     bt = 5e-5 if dt == torch.float32 else 2.5e-2
     assert_close("win.dqkv", dqkv, qr.grad, bt)
     assert_close("win.dbias", dbias.view(H, N, N), br.grad, bt)
+    if ops.win_attn_bwd_fuses_qkv_bias(Q, hd):
+        # the qkv Linear's bias gradient rides on the MFMA kernel: same dqkv bits, sums of dqkv
+        dqkv2 = torch.empty_like(dqkv)
+        qb = torch.full((3 * C,), float("nan"), device="cuda")
+        ops.win_attn_bwd(Q, do.to("cuda", dt).contiguous(), lse, bd, md, dqkv2, dbias, Bw, H, N, hd, Hh, Ww, ws, shift,
+                         scale, dqkv_bias=qb)
+        assert torch.equal(dqkv2, dqkv)
+        assert_close("win.dqkv_bias", qb, qr.grad.reshape(-1, 3 * C).sum(0), 2.5e-2)
 
 
 def test_relpos_bias_gather_scatter(ops):

@@ -70,7 +70,8 @@ SIGNATURES = {
     "vitmi_win_attn_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
                                      c_i64, c_i64, c_f32, c_vp]),
     "vitmi_win_attn_bwd_workspace": (c_sz, [c_i64, c_i64, c_i64]),
-    "vitmi_win_attn_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_i64,
+    "vitmi_win_attn_bwd_fuses_qkv_bias": (C.c_int, [C.c_int, c_i64]),
+    "vitmi_win_attn_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_i64,
                                      c_i64, c_i64, c_i64, c_i64, c_f32, c_vp, c_sz, c_vp]),
     "vitmi_relpos_bias": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]),
     "vitmi_patch_merge": (C.c_int, [c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_i64, C.c_int, c_vp]),

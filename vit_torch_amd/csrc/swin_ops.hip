@@ -286,6 +286,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const bf16* __re
                                                                const float* __restrict__ bias,
                                                                const float* __restrict__ mask,
                                                                bf16* __restrict__ dqkv, float* __restrict__ dbias_part,
+                                                               float* __restrict__ qkvb_part,
                                                                WinGeom geo, int H, int N, float scale, int64_t Bw,
                                                                int nwaves) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -306,6 +307,11 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const bf16* __re
   const bf16* vb_ = qkv + (2 * H + h) * 32;
   const bf16* dob = dout + h * 32;
 
+  // column sums of dQ / dK / dV over this wave's windows (the qkv Linear's bias gradient);
+  // padded queries / keys contribute exact zeros, so no masking is needed
+  f32x4 cq[2], ck[2], cv[2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db) { cq[db] = f32x4{0.f, 0.f, 0.f, 0.f}; ck[db] = cq[db]; cv[db] = cq[db]; }
   f32x4 dsum[4][4];                                // [kb][qb] running d(score) of this head
 #pragma unroll
   for (int kb = 0; kb < 4; ++kb)
@@ -397,6 +403,8 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const bf16* __re
 #pragma unroll
           for (int db = 0; db < 2; ++db) win_store_T(row + db * 16, dv[db][kb], 1.f, g);
         }
+#pragma unroll
+        for (int db = 0; db < 2; ++db) cv[db] += dv[db][kb];
       }
     }
     // ---- dS -> the same tile; dK^T[d][key] = scale * sum_q Q^T[d][q] dS[q][key]
@@ -431,6 +439,8 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const bf16* __re
 #pragma unroll
           for (int db = 0; db < 2; ++db) win_store_T(row + db * 16, dk[db][kb], scale, g);
         }
+#pragma unroll
+        for (int db = 0; db < 2; ++db) ck[db] += dk[db][kb];
       }
     }
     // ---- dQ^T[d][q] = scale * sum_key K^T[d][key] dS^T[key][q]   (B = the dS accumulators)
@@ -460,8 +470,30 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const bf16* __re
 #pragma unroll
           for (int db = 0; db < 2; ++db) win_store_T(row + db * 16, dq[db][qb], scale, g);
         }
+#pragma unroll
+        for (int db = 0; db < 2; ++db) cq[db] += dq[db][qb];
       }
     }
+  }
+  if (qkvb_part) {
+    // fold the 16 lanes of a group (they hold different rows of the same d), lane i == 0 stores
+    // d = 16*db + 4g + r; row wid / H of [nwaves / H][3][H][32]
+    float* brow = qkvb_part + (int64_t)(wid / H) * 3 * H * 32 + h * 32;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = cq[db][r] * scale, b = ck[db][r] * scale, c = cv[db][r];
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+          a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); c += __shfl_xor(c, off, 64);
+        }
+        if (i == 0) {
+          brow[db * 16 + 4 * g + r] = a;
+          brow[H * 32 + db * 16 + 4 * g + r] = b;
+          brow[2 * H * 32 + db * 16 + 4 * g + r] = c;
+        }
+      }
   }
   // partial d(bias): row wid / H of [nwaves / H][H][N][N]
   float* prow = dbias_part + ((int64_t)(wid / H) * H + h) * N * N;
@@ -679,14 +711,20 @@ extern "C" size_t vitmi_win_attn_bwd_workspace(int64_t Bw, int64_t H, int64_t N)
   // delta [Bw,H,N] + per-window (vector kernels) or per-wave (MFMA kernel, <= 1024 waves)
   // partial d(bias) tiles
   int64_t rows = Bw > 1024 / (H > 0 ? H : 1) + 1 ? Bw : 1024 / (H > 0 ? H : 1) + 1;
-  return (size_t)(Bw * H * N) * sizeof(float) + (size_t)(rows * H * N * N) * sizeof(float);
+  return (size_t)(Bw * H * N) * sizeof(float) + (size_t)(rows * H * N * N) * sizeof(float) +
+         (size_t)(1024 / (H > 0 ? H : 1) + 1) * 3 * H * 64 * sizeof(float);   // + qkv-bias partials
 }
 
 // dbias [H,N,N] fp32 (overwritten) = sum over windows of d(score)
+extern "C" int vitmi_win_attn_bwd_fuses_qkv_bias(int dtype, int64_t hd) {
+  return dtype == VITMI_BF16 && hd == 32 && g_win_mfma != 0 ? 1 : 0;
+}
+
 extern "C" int vitmi_win_attn_bwd(const void* qkv, const void* dout, const float* lse, const float* bias,
-                                  const float* mask, void* dqkv, float* dbias, int dtype, int64_t Bw, int64_t H,
-                                  int64_t N, int64_t hd, int64_t Himg, int64_t Wimg, int64_t ws, int64_t shift,
-                                  float scale, void* workspace, size_t workspace_bytes, void* stream_) {
+                                  const float* mask, void* dqkv, float* dbias, float* dqkv_bias, int dtype,
+                                  int64_t Bw, int64_t H, int64_t N, int64_t hd, int64_t Himg, int64_t Wimg,
+                                  int64_t ws, int64_t shift, float scale, void* workspace, size_t workspace_bytes,
+                                  void* stream_) {
   VITMI_REQUIRE(qkv && dout && lse && bias && dqkv && dbias, VITMI_E_BADARG, "win_attn_bwd: null argument");
   int rc = win_check(Bw, H, N, hd, Himg, Wimg, ws, shift, "win_attn_bwd");
   if (rc) return rc;
@@ -708,11 +746,15 @@ extern "C" int vitmi_win_attn_bwd(const void* qkv, const void* dout, const float
       if (err != hipSuccess) return vitmi_fail((int)err, "win_attn_bwd: cannot raise dynamic LDS: %s", hipGetErrorString(err));
       attr = true;
     }
+    float* qb_part = dqkv_bias ? part + per_head * H * N * N : nullptr;     // [per_head][3*H*32]
     hipLaunchKernelGGL(kern, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 4 * WIN_BWD_LDS, stream, (const bf16*)qkv,
-                       (const bf16*)dout, lse, bias, mask, (bf16*)dqkv, part, g, (int)H, (int)N, scale, Bw, nwaves);
+                       (const bf16*)dout, lse, bias, mask, (bf16*)dqkv, part, qb_part, g, (int)H, (int)N, scale, Bw, nwaves);
     if ((rc = vitmi_check_launch("win_attn_bwd_mfma_kernel"))) return rc;
-    return vitmi_reduce_rows(part, (int)per_head, H * N * N, H * N * N, dbias, stream);
+    if ((rc = vitmi_reduce_rows(part, (int)per_head, H * N * N, H * N * N, dbias, stream))) return rc;
+    if (dqkv_bias) return vitmi_reduce_rows(qb_part, (int)per_head, 3 * H * 32, 3 * H * 32, dqkv_bias, stream);
+    return 0;
   }
+  VITMI_REQUIRE(!dqkv_bias, VITMI_E_DTYPE, "win_attn_bwd: dqkv_bias is produced by the bf16 hd = 32 kernel only (ask vitmi_win_attn_bwd_fuses_qkv_bias)");
   dim3 grid((unsigned)Bw, (unsigned)H);
   const size_t lds = 4 * 64 * (hd + 1) * sizeof(float);
   if (dtype == VITMI_BF16) {

@@ -325,12 +325,18 @@ def win_attn_fwd(qkv, out, lse, bias, mask, Bw, H, N, hd, Himg, Wimg, ws, shift,
           "vitmi_win_attn_fwd")
 
 
-def win_attn_bwd(qkv, dout, lse, bias, mask, dqkv, dbias, Bw, H, N, hd, Himg, Wimg, ws, shift, scale):
+def win_attn_bwd_fuses_qkv_bias(t, hd) -> bool:
+    return bool(load().vitmi_win_attn_bwd_fuses_qkv_bias(dtype_code(t), hd))
+
+
+def win_attn_bwd(qkv, dout, lse, bias, mask, dqkv, dbias, Bw, H, N, hd, Himg, Wimg, ws, shift, scale,
+                 dqkv_bias=None):
+    """dqkv_bias: fp32 [3*H*hd] <- column sums of dqkv (only where win_attn_bwd_fuses_qkv_bias)."""
     _need_cuda(qkv, dout, dqkv, dbias)
     lib = load()
     ws_buf = workspace(lib.vitmi_win_attn_bwd_workspace(Bw, H, N), qkv.device)
     check(lib.vitmi_win_attn_bwd(qkv.data_ptr(), dout.data_ptr(), lse.data_ptr(), bias.data_ptr(), _ptr(mask),
-                                 dqkv.data_ptr(), dbias.data_ptr(), dtype_code(qkv), Bw, H, N, hd, Himg, Wimg, ws,
+                                 dqkv.data_ptr(), dbias.data_ptr(), _ptr(dqkv_bias), dtype_code(qkv), Bw, H, N, hd, Himg, Wimg, ws,
                                  shift, float(scale), ws_buf.data_ptr(), ws_buf.numel(), _stream()),
           "vitmi_win_attn_bwd")
 

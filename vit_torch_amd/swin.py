@@ -456,13 +456,15 @@ class SwinEngine:
                 self._gemm(Gb, O, pk.g(a.proj.weight), a_kmajor=False, b_kmajor=False)
                 dqkv = new(M, 3 * C, T)
                 dbias = torch.empty(H * N * N, dtype=f32, device=dev)
-                ops.win_attn_bwd(qkv, dO, lse, bias, blk.attn_mask, dqkv, dbias, Bw, H, N, hd, Hh, Ww, ws, sh, a.scale)
+                fuse_qb = a.qkv.bias is not None and ops.win_attn_bwd_fuses_qkv_bias(qkv, hd)
+                ops.win_attn_bwd(qkv, dO, lse, bias, blk.attn_mask, dqkv, dbias, Bw, H, N, hd, Hh, Ww, ws, sh, a.scale,
+                                 dqkv_bias=pk.g(a.qkv.bias) if fuse_qb else None)
                 ops.relpos_bias_scatter(dbias, a.relative_position_index, pk.g(a.relative_position_bias_table),
                                         a.relative_position_bias_table.shape[0], H, N)
                 dln1 = new(M, C, T)
                 self._gemm(dqkv, self._w(a.qkv.weight), dln1, b_kmajor=False)
                 self._gemm(dqkv, ln1, pk.g(a.qkv.weight), a_kmajor=False, b_kmajor=False)
-                if a.qkv.bias is not None:
+                if a.qkv.bias is not None and not fuse_qb:
                     ops.colsum(dqkv, pk.g(a.qkv.bias))
                 prev_bias = blist[bi - 1].mlp.fc2.bias if bi > 0 else None
                 ops.layernorm_bwd(dln1, X, mean1, rstd1, pk.f32(blk.norm1.weight), G, G, Gb,
