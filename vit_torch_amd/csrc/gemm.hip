@@ -217,7 +217,7 @@ int gemm_small_launch(const GemmArgs& g, int form, hipStream_t stream);
 static int g_small_override = -1;    // diagnostic / test hook: 0 = never, 1 = also when impl == GENERIC, -1 = default
 extern "C" void vitmi_debug_gemm_small(int mode) { g_small_override = mode; }
 static bool small_lds_ok(const GemmArgs& g, int form) {
-  if (form == 0) return true;
+  if (form == 0) return ((g.N + 15) / 16 * 16) * (64 * 2 + 16) <= 96 * 1024;
   const int64_t Kp = (g.K + 31) / 32 * 32, Mp = (g.M + 15) / 16 * 16;
   const int64_t ry = g.N * 2 + (((g.N * 2) % 128 == 0) ? 32 : 0), rs = Mp * 2 + (((Mp * 2) % 128 == 0) ? 32 : 0);
   return Kp * ry + (form == 2 ? 64 * rs : 0) <= 96 * 1024;

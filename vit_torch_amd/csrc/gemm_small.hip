@@ -66,6 +66,23 @@ __device__ __forceinline__ void store_tile(bf16* C, int64_t ldc, int m0, int n0,
     if (m < M) C[(int64_t)m * ldc + n] = (bf16)(acc[r] * alpha);
   }
 }
+// transposed accumulator: lane owns row m0 + (lane & 15), columns n0 + 4*(lane >> 4) + r
+__device__ __forceinline__ void store_tile_T(bf16* C, int64_t ldc, int m0, int n0, int M, int N, const f32x4& acc,
+                                             float alpha, int lane) {
+  const int m = m0 + (lane & 15), n = n0 + 4 * (lane >> 4);
+  if (m >= M || n >= N) return;
+  bf16* p = C + (int64_t)m * ldc + n;
+  if (n + 4 <= N && (ldc & 3) == 0 && ((uintptr_t)C & 7) == 0) {
+    bf16x4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = (bf16)(acc[r] * alpha);
+    *reinterpret_cast<bf16x4*>(p) = v;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (n + r < N) p[r] = (bf16)(acc[r] * alpha);
+  }
+}
 __device__ __forceinline__ int y_pitch(int N) { return N * 2 + (((N * 2) % 128 == 0) ? 32 : 0); }
 
 // rows [r0, r0 + rows) x [0, cols) of X -> LDS image (pitch RS), zero outside (R_total, cols)
@@ -99,22 +116,29 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(SmallArgs a) {
 
   if constexpr (FORM == 0) {
     const int ksteps = (K + 31) / 32;              // <= 2 (host checks K <= 64)
+    // Y (the B rows) is staged once in LDS: every wave walks all of its column tiles, and an
+    // L2 round trip per tile (two waves per SIMD cannot hide it) was the whole run time
+    const int RSB = 64 * 2 + 16;                   // 64 k (zero beyond K) + pad: conflict-free row reads
+    stage_rows(smem, RSB, B, a.ldb, 0, tiles_n * 16, N, K, 64, tid, 256);
+    __syncthreads();
     for (int rt = w; rt < tiles_m; rt += 4) {
       const int row = min(rt * 16 + li, M - 1);
       bf16x8 af[2];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) af[ks] = ks < ksteps ? row_frag(A, a.lda, row, ks * 32 + 8 * g, K) : zero8();
       for (int ct = 0; ct < tiles_n; ++ct) {
-        const int col = min(ct * 16 + li, N - 1);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           if (ks < ksteps) {
-            const bf16x8 bf = row_frag(B, a.ldb, col, ks * 32 + 8 * g, K);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], bf, acc, 0, 0, 0);
+            const bf16x8 bf = *reinterpret_cast<const bf16x8*>(smem + (ct * 16 + li) * RSB + (ks * 32 + 8 * g) * 2);
+            // operands swapped: D^T[j][i], so the lane owns row i of C and 4 CONSECUTIVE
+            // columns j: one 8-byte store instead of four 2-byte ones (this form writes
+            // N x N scores per problem and is store-issue bound)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, af[ks], acc, 0, 0, 0);
           }
         }
-        store_tile(C, a.ldc, rt * 16, ct * 16, M, N, acc, a.alpha, lane);
+        store_tile_T(C, a.ldc, rt * 16, ct * 16, M, N, acc, a.alpha, lane);
       }
     }
   } else {
@@ -191,7 +215,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(SmallArgs a) {
 }
 
 inline size_t small_lds(int form, int M, int N, int K) {
-  if (form == 0) return 0;
+  if (form == 0) return (size_t)((N + 15) / 16 * 16) * (64 * 2 + 16);
   const int Kp = (K + 31) / 32 * 32;
   const int RSY = N * 2 + (((N * 2) % 128 == 0) ? 32 : 0);
   size_t b = (size_t)Kp * RSY;
@@ -234,7 +258,7 @@ int gemm_small_launch(const GemmArgs& g, int form, hipStream_t stream) {
   do {                                                                                                \
     auto kern = gemm_small_kernel<F>;                                                                 \
     static bool attr = false;                                                                         \
-    if (!attr && F != 0) {                                                                            \
+    if (!attr) {                                                                            \
       hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);    \
       if (err != hipSuccess) return vitmi_fail((int)err, "gemm_small: cannot raise dynamic LDS: %s", hipGetErrorString(err)); \
