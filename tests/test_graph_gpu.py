@@ -58,3 +58,21 @@ def test_graph_recaptures_when_the_learning_rate_changes(lib):
     opt.param_groups[0]["lr"] = 1e-3
     step(x, y)
     assert step.graph is not g0, "a new LR must not be replayed with the old kernel argument"
+
+
+def test_network_harness_with_hip_graph_matches_eager_harness(lib):
+    """Network(hip_graph=True): first batch eager (+capture), same-shape batches replayed, the
+    short last batch eager; two epochs with an LR step in between (re-capture)."""
+    from vit_torch_amd.network import Network
+    data = _batches(4)
+    data.append((data[0][0][:40].clone(), data[0][1][:40].clone()))        # ragged last batch
+    hist = {}
+    for use_graph in (False, True):
+        m, _, _ = _make()
+        net = Network(m, opt="sgd", lr=5e-2, lr_type="step", lr_step=1, lr_gamma=0.5, hip_graph=use_graph)
+        hist[use_graph] = net.fit(data, epochs=2)
+        hist[use_graph].append(m.engine().pack.flat.clone())
+    for e in range(2):
+        assert hist[True][e]["train"]["loss"] == pytest.approx(hist[False][e]["train"]["loss"], rel=1e-5, abs=1e-6)
+        assert (hist[True][e]["train"]["correct"] == hist[False][e]["train"]["correct"]).all()
+    torch.testing.assert_close(hist[True][2], hist[False][2], rtol=1e-5, atol=1e-6)

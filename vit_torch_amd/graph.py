@@ -10,6 +10,10 @@ removes it.  Static shapes only: the graph owns input buffers that each call cop
     for x, y in loader:
         loss = step(x, y)           # device tensor, valid until the next call
 
+`warmup` eager steps run on the example batch before the capture (they DO update the
+parameters; lazy initialisation — LDS attributes, side stream, workspaces — must not happen
+inside a capture, so at least one is needed the first time).  `warm_out` / `warm_loss` hold
+the last warm-up step's logits and loss, for callers that account for that batch.
 Limits (checked or documented): parameters must only be changed by the captured optimizer
 between replays (re-capture after load_state_dict or a learning-rate change: the LR is a
 kernel argument baked into the graph; `step.recapture()`), single process (the RCCL
@@ -36,8 +40,10 @@ class GraphedStep:
         self.graph = None
         self.loss = None
         self.out = None
+        self.warm_out = None
+        self.warm_loss = None
         self._lrs = None
-        self.recapture()
+        self.recapture(self.warmup)
 
     def _eager(self):
         self.optimizer.zero_grad(set_to_none=True)
@@ -47,8 +53,9 @@ class GraphedStep:
         self.optimizer.step()
         return out, loss
 
-    def recapture(self):
-        """(Re)build the graph from the current parameters and optimizer settings."""
+    def recapture(self, warmup: int = 0):
+        """(Re)build the graph from the current parameters and optimizer settings; `warmup`
+        eager steps first (0 for a re-capture: everything is initialised already)."""
         self.graph = None
         # the warm-up passes run on a side stream (torch's capture recipe), so AccumulateGrad
         # nodes of earlier eager steps live on another stream: expected here, not a hazard
@@ -58,8 +65,9 @@ class GraphedStep:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                 # warm-up off the default stream: lazy
-            for _ in range(self.warmup):              # initialisation (LDS attributes, side
-                self._eager()                         # streams, workspaces) happens eagerly
+            for _ in range(warmup):                   # initialisation (LDS attributes, side
+                out, loss = self._eager()             # streams, workspaces) happens eagerly
+                self.warm_out, self.warm_loss = out.detach().clone(), loss.detach().clone()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()

@@ -91,7 +91,7 @@ class Network:
     }
 
     def __init__(self, model, opt="sgd", loss_fn=None, lr=1e-3, lr_type="step", lr_step=10, lr_gamma=0.5,
-                 lr_scale=0.1, device="cuda", epochs=1):
+                 lr_scale=0.1, device="cuda", epochs=1, hip_graph=False):
         if not isinstance(model, nn.Module):
             raise ValueError("`model` must be a torch.nn.Module")          # utils_network.py:167-170
         self.model = model.to(device)
@@ -104,6 +104,10 @@ class Network:
             self.model.engine()
         self.optimizer = self.optimizer_fns[opt](self.model.parameters(), lr)
         self.lr_scheduler = get_lr_scheduler(self.optimizer, lr_type, lr_step, lr_gamma, lr_scale)
+        # hip_graph: training steps replay a captured HIP graph (vit_torch_amd.graph.GraphedStep);
+        # batches of another shape (the last, short batch of an epoch) run eagerly
+        self.hip_graph = bool(hip_graph)
+        self._graphed = None
 
     def run_one_epoch(self, dataloader: Iterable, training: bool = True):
         losses: List[torch.Tensor] = []
@@ -111,7 +115,23 @@ class Network:
         for inputs, labels in dataloader:
             inputs = inputs.to(self.device)
             labels = labels.to(self.device)
-            if training:
+            if training and self.hip_graph:
+                g = self._graphed
+                if g is None and inputs.is_cuda:
+                    from .graph import GraphedStep
+                    # one eager step on this batch (it counts as the batch's update), then the capture
+                    g = self._graphed = GraphedStep(self.model, self.loss_fn, self.optimizer, inputs, labels, warmup=1)
+                    outputs, loss = g.warm_out, g.warm_loss
+                elif g is not None and inputs.shape == g.x.shape and labels.shape == g.y.shape:
+                    loss = g(inputs, labels).clone()
+                    outputs = g.out.clone()
+                else:
+                    outputs = self.model(inputs)
+                    loss = self.loss_fn(outputs, labels)
+                    self.optimizer.zero_grad()
+                    loss.backward()
+                    self.optimizer.step()
+            elif training:
                 outputs = self.model(inputs)
                 loss = self.loss_fn(outputs, labels)
                 self.optimizer.zero_grad()
