@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--img", type=int, default=224)
     ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--residual", default="fp32", choices=["bf16", "fp32"])
+    ap.add_argument("--mode", default="finetune", choices=["finetune", "lineareval"],
+                    help="lineareval: frozen backbone under no_grad + a 10-class head trained on its features "
+                         "(the reference's --lineareval, main.py:184-201)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the step from a captured HIP graph (single GPU; auto = try, fall back to eager)")
@@ -77,7 +80,7 @@ def build_model(arch, img, compute, residual):
     return VisionModelZoo.get_model(arch, pretrained=False, classifier=10, **kw)
 
 
-def cpu_baseline(arch, img, batch, steps):
+def cpu_baseline(arch, img, batch, steps, mode="finetune"):
     """Oracle timed on the host cores (test infrastructure used as the CPU baseline)."""
     import torch.nn.functional as F
     from oracle import vit_ref
@@ -91,15 +94,29 @@ def cpu_baseline(arch, img, batch, steps):
     torch.set_num_threads(cores)
     model = build_oracle(arch, img)
     vit_ref.seeded_init_(model, 1)
-    opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9)
     g = torch.Generator("cpu").manual_seed(0)
     x = torch.randn(batch, 3, img, img, generator=g)
     y = torch.randint(0, 10, (batch,), generator=g)
+    if mode == "lineareval":       # frozen trunk, only the head (the model's last Linear) trains
+        head = model.head
+        model.head = torch.nn.Identity()
+        if hasattr(model, "apply_head"):
+            model.apply_head = False
+        opt = torch.optim.SGD(head.parameters(), lr=1e-3, momentum=0.9)
 
-    def step():
-        opt.zero_grad()
-        F.cross_entropy(model(x), y).backward()
-        opt.step()
+        def step():
+            with torch.no_grad():
+                feat = model(x)
+            opt.zero_grad()
+            F.cross_entropy(head(feat), y).backward()
+            opt.step()
+    else:
+        opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9)
+
+        def step():
+            opt.zero_grad()
+            F.cross_entropy(model(x), y).backward()
+            opt.step()
 
     step()                                   # warm-up
     t0 = time.perf_counter()
@@ -108,7 +125,7 @@ def cpu_baseline(arch, img, batch, steps):
     dt = time.perf_counter() - t0
     return {"value": round(batch * steps / dt, 3), "unit": "images/sec", "cores": cores,
             "threads": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} steps of {arch} fwd+CE+bwd+SGD at batch {batch}, {img}x{img}, fp32, after 1 warm-up"}
+            "sample": f"{steps} steps of {arch} {mode} at batch {batch}, {img}x{img}, fp32, after 1 warm-up"}
 
 
 def main():
@@ -131,23 +148,51 @@ def main():
     torch.manual_seed(1)
     model = build_model(a.arch, a.img, a.compute, a.residual).to(dev)
     model.train()
+    head = None
+    if a.mode == "lineareval":
+        # backbone without a head + a stand-alone ClassifierHead, as main.py:184-201 composes them
+        from vit_torch_amd import VisionModelZoo
+        feat_dim = model.norm.weight.shape[-1]
+        model.head = torch.nn.Identity()
+        if hasattr(model, "head_dist"):
+            model.head_dist = model.head
+        if hasattr(model, "apply_head"):
+            model.apply_head = False
+        for p_ in model.parameters():
+            p_.requires_grad_(False)
+        head = VisionModelZoo.get_classifier_head(feat_dim, [10]).to(dev)
     g = torch.Generator("cpu").manual_seed(1000 + rank)     # per-rank shard of the global batch
     x = torch.randn(a.batch, 3, a.img, a.img, generator=g).to(dev)
     y = torch.randint(0, 10, (a.batch,), generator=g).to(dev)
     crit = CrossEntropyLoss()
     eng = model.engine()
-    reducer = GradReducer(eng.pack) if world > 1 else None
-    if reducer is not None:
-        reducer.broadcast_parameters(0)
-        eng.reducer = reducer
-    opt = FusedSGD(model.parameters(), lr=1e-3, momentum=0.9, grad_scale=1.0 / world)
+    if head is not None:
+        if world > 1:
+            raise SystemExit("--mode lineareval is a single-GPU measurement")
+        reducer = None
+        opt = FusedSGD(head.engine().parameters(), lr=1e-3, momentum=0.9)
 
-    def eager_step():
-        opt.zero_grad()
-        loss = crit(model(x), y)
-        loss.backward()
-        opt.step()
-        return loss
+        def eager_step():
+            with torch.no_grad():
+                feat = model(x)
+            opt.zero_grad()
+            loss = crit(head(feat), y)
+            loss.backward()
+            opt.step()
+            return loss
+    else:
+        reducer = GradReducer(eng.pack) if world > 1 else None
+        if reducer is not None:
+            reducer.broadcast_parameters(0)
+            eng.reducer = reducer
+        opt = FusedSGD(model.parameters(), lr=1e-3, momentum=0.9, grad_scale=1.0 / world)
+
+        def eager_step():
+            opt.zero_grad()
+            loss = crit(model(x), y)
+            loss.backward()
+            opt.step()
+            return loss
 
     def quick_ms(fn, n=3):
         fn()
@@ -159,7 +204,7 @@ def main():
         return (time.perf_counter() - t) / n * 1e3
 
     step, graphed = eager_step, False
-    if world == 1 and a.graph != "off":
+    if world == 1 and a.graph != "off" and head is None:
         try:
             from vit_torch_amd.graph import GraphedStep
             gs = GraphedStep(model, crit, opt, x, y)
@@ -235,19 +280,23 @@ def main():
 
     cpu = None
     if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(a.arch, a.img, a.cpu_batch, a.cpu_steps)
+        cpu = cpu_baseline(a.arch, a.img, a.cpu_batch, a.cpu_steps, a.mode)
 
     if rank == 0:
         ips = a.batch * world * a.steps / elapsed
-        flop_img = GFLOP_PER_IMAGE if (a.arch == "dino_vitb16" and a.img == 224) else None
+        flop_img = None
+        if a.arch == "dino_vitb16" and a.img == 224:
+            flop_img = GFLOP_PER_IMAGE if a.mode == "finetune" else GFLOP_PER_IMAGE / 3.0   # forward only
         out = {
-            "metric": ("images/sec fwd+bwd ViT-B/16 224^2 bs=256/GPU" if (a.arch == "dino_vitb16" and a.img == 224 and a.batch == 256)
-                       else f"images/sec fwd+bwd {a.arch} {a.img}^2 bs={a.batch}/GPU"),
+            "metric": ("images/sec fwd+bwd ViT-B/16 224^2 bs=256/GPU" if (a.arch == "dino_vitb16" and a.img == 224 and a.batch == 256 and a.mode == "finetune")
+                       else f"images/sec {'lineareval' if a.mode == 'lineareval' else 'fwd+bwd'} {a.arch} {a.img}^2 bs={a.batch}/GPU"),
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.compute, "data": "synthetic",
-            "config": {"workload": f"{a.arch} {a.img}x{a.img} fwd+CE+bwd+SGD(momentum) step, "
+            "config": {"workload": (f"{a.arch} {a.img}x{a.img} fwd+CE+bwd+SGD(momentum) step, " if a.mode == "finetune" else
+                                    f"{a.arch} {a.img}x{a.img} linear evaluation step (frozen backbone forward under no_grad + "
+                                    f"Linear(D,10) head fwd+CE+bwd+SGD), ") +
                                    f"batch {a.batch}/GPU, 10 classes, random-init weights",
                        "global_batch": a.batch * world, "residual_stream": a.residual,
                        "parallelism": f"dp{world}", "hip_graph": graphed},

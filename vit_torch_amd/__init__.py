@@ -7,5 +7,7 @@ from .vit import VisionTransformer  # noqa: F401
 from .cait import cait_models  # noqa: F401
 from .swin import SwinTransformer  # noqa: F401
 from .graph import GraphedStep  # noqa: F401
+from .head import ClassifierHead  # noqa: F401
+from .checkpoint import load_reference_checkpoint  # noqa: F401
 
-__all__ = ["VisionModelZoo", "VisionTransformer", "CrossEntropyLoss", "FusedSGD", "GraphedStep", "VitmiError"]
+__all__ = ["VisionModelZoo", "VisionTransformer", "CrossEntropyLoss", "FusedSGD", "GraphedStep", "ClassifierHead", "load_reference_checkpoint", "VitmiError"]

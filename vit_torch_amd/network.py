@@ -91,16 +91,23 @@ class Network:
     }
 
     def __init__(self, model, opt="sgd", loss_fn=None, lr=1e-3, lr_type="step", lr_step=10, lr_gamma=0.5,
-                 lr_scale=0.1, device="cuda", epochs=1, hip_graph=False):
+                 lr_scale=0.1, device="cuda", epochs=1, hip_graph=False, frozen_model_bottom=None):
         if not isinstance(model, nn.Module):
             raise ValueError("`model` must be a torch.nn.Module")          # utils_network.py:167-170
         self.model = model.to(device)
         self.device = device
+        # linear evaluation (utils_network.py:143,202-206): frozen backbones run first, under
+        # no_grad (:413-415), and only `model` (the head) is trained
+        if isinstance(frozen_model_bottom, nn.Module):
+            frozen_model_bottom = [frozen_model_bottom]
+        self.frozen_model_bottom = [m.to(device) for m in frozen_model_bottom] if isinstance(frozen_model_bottom, list) else []
         self.loss_fn = loss_fn if loss_fn is not None else CrossEntropyLoss()
         self.epochs = epochs
         if opt not in self.optimizer_fns:
             raise ValueError(f"optimizer `{opt}` is not supported")
         if opt == "sgd":        # the flat buffers exist after the engine is built
+            if not hasattr(self.model, "engine"):
+                raise ValueError("optimizer `sgd` (FusedSGD) needs a vit_torch_amd model or ClassifierHead")
             self.model.engine()
         self.optimizer = self.optimizer_fns[opt](self.model.parameters(), lr)
         self.lr_scheduler = get_lr_scheduler(self.optimizer, lr_type, lr_step, lr_gamma, lr_scale)
@@ -115,6 +122,10 @@ class Network:
         for inputs, labels in dataloader:
             inputs = inputs.to(self.device)
             labels = labels.to(self.device)
+            if self.frozen_model_bottom:
+                with torch.no_grad():
+                    for m in self.frozen_model_bottom:
+                        inputs = m(inputs)
             if training and self.hip_graph:
                 g = self._graphed
                 if g is None and inputs.is_cuda:

@@ -134,6 +134,11 @@ class VisionModelZoo:
                 linear_layers.append(nn.Linear(in_features=fin, out_features=v, bias=is_not_last))
                 if is_not_last:
                     linear_layers.append(classifier_act)
+        # same structure / state-dict keys as the reference's nn.Sequential; stand-alone
+        # (linear evaluation) it runs on libvitmi kernels too (head.py)
+        if all(isinstance(m, (nn.Linear, nn.GELU)) for m in linear_layers):
+            from .head import ClassifierHead
+            return ClassifierHead(*linear_layers)
         return nn.Sequential(*linear_layers)
 
     @classmethod
