@@ -280,6 +280,14 @@ int vitmi_sgd_momentum(float* p, const float* g, float* buf, void* p_shadow_bf16
                        int64_t n, float lr, float momentum, float grad_scale,
                        void* stream);
 
+/* optim.Adam / optim.AdamW step (utils_network.py:121,124; torch defaults betas (0.9, 0.999),
+ * eps 1e-8, AdamW weight_decay 1e-2) over a flat buffer.  state[0] (device, fp32) is the step
+ * count: it is advanced by this call BEFORE the update, so a captured HIP graph replays the
+ * right bias corrections.  decoupled != 0: AdamW (p *= 1 - lr*wd); else L2 (g += wd*p). */
+int vitmi_adam(float* p, const float* g, float* m, float* v, void* p_shadow_bf16, float* state,
+               int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+               int decoupled, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,7 +1,7 @@
 """vit_torch_amd — MI355X-native ViT forward/backward training path (libvitmi)."""
 from ._lib import VitmiError  # noqa: F401
 from .loss import CrossEntropyLoss  # noqa: F401
-from .optim import FusedSGD  # noqa: F401
+from .optim import FusedAdamW, FusedSGD  # noqa: F401
 from .vision_all import VisionModelZoo  # noqa: F401
 from .vit import VisionTransformer  # noqa: F401
 from .cait import cait_models  # noqa: F401
@@ -10,4 +10,4 @@ from .graph import GraphedStep  # noqa: F401
 from .head import ClassifierHead  # noqa: F401
 from .checkpoint import load_reference_checkpoint  # noqa: F401
 
-__all__ = ["VisionModelZoo", "VisionTransformer", "CrossEntropyLoss", "FusedSGD", "GraphedStep", "ClassifierHead", "load_reference_checkpoint", "VitmiError"]
+__all__ = ["VisionModelZoo", "VisionTransformer", "CrossEntropyLoss", "FusedSGD", "FusedAdamW", "GraphedStep", "ClassifierHead", "load_reference_checkpoint", "VitmiError"]

@@ -272,6 +272,36 @@ __global__ void sgd_momentum_kernel(float* __restrict__ p, const float* __restri
   }
 }
 
+// ------------------------------------------------------------------ adam --
+// torch.optim.Adam / AdamW single-tensor update (decoupled decay when `decoupled`):
+//   p *= 1 - lr*wd (AdamW)  |  g += wd*p (Adam);  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2
+//   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// The step count t lives on the DEVICE (state[0]) and is advanced by a one-thread kernel
+// before the update, so a captured HIP graph replays the right bias corrections.
+__global__ void adam_tick_kernel(float* state) { state[0] += 1.f; }
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, bf16* __restrict__ shadow, const float* __restrict__ state,
+                            int64_t n, float lr, float b1, float b2, float eps, float wd, int decoupled,
+                            float gscale) {
+  const float t = state[0];
+  const float bc1 = 1.f - powf(b1, t), bc2s = sqrtf(1.f - powf(b2, t));
+  const float step = lr / bc1;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float pi = p[i], gi = g[i] * gscale;
+    if (decoupled) pi *= 1.f - lr * wd;
+    else gi = fmaf(wd, pi, gi);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    pi -= step * mi / (sqrtf(vi) / bc2s + eps);
+    p[i] = pi;
+    if (shadow) shadow[i] = (bf16)pi;
+  }
+}
+
 }  // namespace
 
 int vitmi_reduce_rows3(const float* part, int S, int64_t N, int64_t ld, float* out0, float* out1, float* out2,
@@ -389,6 +419,20 @@ extern "C" int vitmi_softmax_xent(const float* logits, const int64_t* labels, fl
   if (rc) return rc;
   hipLaunchKernelGGL(xent_reduce_kernel, dim3(1), dim3(256), 0, stream, loss + 1, correct + 1, loss, correct, B);
   return vitmi_check_launch("xent_reduce_kernel");
+}
+
+extern "C" int vitmi_adam(float* p, const float* g, float* m, float* v, void* shadow, float* state, int64_t n,
+                          float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled,
+                          float grad_scale, void* stream_) {
+  VITMI_REQUIRE(p && g && m && v && state && n > 0, VITMI_E_BADARG, "adam: bad argument");
+  VITMI_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, VITMI_E_BADARG, "adam: bad hyper-parameter");
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, stream, state);
+  int rc = vitmi_check_launch("adam_tick_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, stream, p, g, m, v, (bf16*)shadow, state, n, lr,
+                     beta1, beta2, eps, weight_decay, decoupled, grad_scale);
+  return vitmi_check_launch("adam_kernel");
 }
 
 extern "C" int vitmi_sgd_momentum(float* p, const float* g, float* buf, void* shadow, int64_t n,

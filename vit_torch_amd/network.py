@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 
 from .loss import CrossEntropyLoss
-from .optim import FusedSGD
+from .optim import FusedAdamW, FusedSGD
 
 
 class LRSchedule:
@@ -86,8 +86,9 @@ class Network:
     optimizer_fns = {
         "sgd": lambda params, lr: FusedSGD(params, lr=lr, momentum=0.9),      # utils_network.py:120
         "torch_sgd": lambda params, lr: torch.optim.SGD(params, lr=lr, momentum=0.9),
-        "adam": lambda params, lr: torch.optim.Adam(params, lr=lr),
-        "adamw": lambda params, lr: torch.optim.AdamW(params, lr=lr),
+        "adam": lambda params, lr: FusedAdamW(params, lr=lr, weight_decay=0.0, decoupled=False),   # utils_network.py:121
+        "adamw": lambda params, lr: FusedAdamW(params, lr=lr),                                     # utils_network.py:124
+        "torch_adamw": lambda params, lr: torch.optim.AdamW(params, lr=lr),
     }
 
     def __init__(self, model, opt="sgd", loss_fn=None, lr=1e-3, lr_type="step", lr_step=10, lr_gamma=0.5,
@@ -105,9 +106,9 @@ class Network:
         self.epochs = epochs
         if opt not in self.optimizer_fns:
             raise ValueError(f"optimizer `{opt}` is not supported")
-        if opt == "sgd":        # the flat buffers exist after the engine is built
+        if opt in ("sgd", "adam", "adamw"):     # the flat buffers exist after the engine is built
             if not hasattr(self.model, "engine"):
-                raise ValueError("optimizer `sgd` (FusedSGD) needs a vit_torch_amd model or ClassifierHead")
+                raise ValueError(f"optimizer `{opt}` (fused) needs a vit_torch_amd model or ClassifierHead")
             self.model.engine()
         self.optimizer = self.optimizer_fns[opt](self.model.parameters(), lr)
         self.lr_scheduler = get_lr_scheduler(self.optimizer, lr_type, lr_step, lr_gamma, lr_scale)

@@ -265,6 +265,15 @@ def sgd_momentum(p, g, buf, shadow, lr, momentum, grad_scale=1.0):
                                     _stream()), "vitmi_sgd_momentum")
 
 
+def adam(p, g, m, v, shadow, state, lr, beta1, beta2, eps, weight_decay, decoupled, grad_scale=1.0):
+    _need_cuda(p, g, m, v, state)
+    assert p.dtype == g.dtype == m.dtype == v.dtype == state.dtype == torch.float32
+    assert p.numel() == g.numel() == m.numel() == v.numel() and state.numel() >= 1
+    check(load().vitmi_adam(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(shadow), state.data_ptr(),
+                            p.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+                            int(bool(decoupled)), float(grad_scale), _stream()), "vitmi_adam")
+
+
 # ------------------------------------------------------------------ CaiT ops ---
 def th_softmax_fwd(S, Wl, bl, Ww, bw, P, Pm, B, H, N, Nk, ld):
     _need_cuda(S, P, Pm)
