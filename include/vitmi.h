@@ -280,6 +280,15 @@ int vitmi_sgd_momentum(float* p, const float* g, float* buf, void* p_shadow_bf16
                        int64_t n, float lr, float momentum, float grad_scale,
                        void* stream);
 
+/* Device-side input transform (utils_datasets.py:553-582: RandomCrop(S, padding, fill=128),
+ * RandomHorizontalFlip, ToTensor, Normalize): uint8 NHWC [B,H,W,C] -> fp32 NCHW [B,C,S,S].
+ * off_y/off_x [B] = top-left of the crop inside the padded image (NULL -> pad: centred, the
+ * test-time transform), flip [B] (NULL -> none), mean/std [C] (NULL -> 0 / 1).  The random
+ * draws are the caller's; torchvision's arithmetic order, bit-exact in fp32. */
+int vitmi_image_ingest(const void* src_u8_nhwc, float* dst_nchw, const int32_t* off_y, const int32_t* off_x,
+                       const uint8_t* flip, const float* mean, const float* std, int64_t B, int64_t H,
+                       int64_t W, int64_t C, int64_t S, int64_t pad, int64_t fill, void* stream);
+
 /* optim.Adam / optim.AdamW step (utils_network.py:121,124; torch defaults betas (0.9, 0.999),
  * eps 1e-8, AdamW weight_decay 1e-2) over a flat buffer.  state[0] (device, fp32) is the step
  * count: it is advanced by this call BEFORE the update, so a captured HIP graph replays the

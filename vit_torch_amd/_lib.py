@@ -84,6 +84,8 @@ SIGNATURES = {
     "vitmi_colsum": (C.c_int, [c_vp, C.c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_sz, c_vp]),
     "vitmi_softmax_xent": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "vitmi_sgd_momentum": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_vp]),
+    "vitmi_image_ingest": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
+                                     c_i64, c_vp]),
     "vitmi_adam": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, C.c_int,
                              c_f32, c_vp]),
 }

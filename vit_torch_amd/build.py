@@ -28,6 +28,7 @@ SOURCES = [
     "gemm_small.hip",
     "layernorm.hip",
     "elementwise.hip",
+    "ingest.hip",
     "attention.hip",
     "attention_f32.hip",
     "cait_ops.hip",

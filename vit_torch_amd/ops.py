@@ -265,6 +265,20 @@ def sgd_momentum(p, g, buf, shadow, lr, momentum, grad_scale=1.0):
                                     _stream()), "vitmi_sgd_momentum")
 
 
+def image_ingest(src, dst, off_y, off_x, flip, mean, std, pad, fill=128):
+    """src uint8 [B,H,W,C] (NHWC) -> dst fp32 [B,C,S,S]; see vitmi_image_ingest."""
+    _need_cuda(src, dst)
+    assert src.dtype == torch.uint8 and src.is_contiguous() and dst.dtype == torch.float32 and dst.is_contiguous()
+    B, H, W, C = src.shape
+    assert dst.shape[0] == B and dst.shape[1] == C and dst.shape[2] == dst.shape[3]
+    for t, dt in ((off_y, torch.int32), (off_x, torch.int32), (flip, torch.uint8), (mean, torch.float32), (std, torch.float32)):
+        assert t is None or (t.is_cuda and t.dtype == dt and t.is_contiguous())
+    check(load().vitmi_image_ingest(src.data_ptr(), dst.data_ptr(), _ptr(off_y), _ptr(off_x), _ptr(flip), _ptr(mean),
+                                    _ptr(std), B, H, W, C, dst.shape[2], int(pad), int(fill), _stream()),
+          "vitmi_image_ingest")
+    return dst
+
+
 def adam(p, g, m, v, shadow, state, lr, beta1, beta2, eps, weight_decay, decoupled, grad_scale=1.0):
     _need_cuda(p, g, m, v, state)
     assert p.dtype == g.dtype == m.dtype == v.dtype == state.dtype == torch.float32
