@@ -9,5 +9,6 @@ from .swin import SwinTransformer  # noqa: F401
 from .graph import GraphedStep  # noqa: F401
 from .head import ClassifierHead  # noqa: F401
 from .checkpoint import load_reference_checkpoint  # noqa: F401
+from .stats import RunLog  # noqa: F401
 
-__all__ = ["VisionModelZoo", "VisionTransformer", "CrossEntropyLoss", "FusedSGD", "FusedAdamW", "GraphedStep", "ClassifierHead", "load_reference_checkpoint", "VitmiError"]
+__all__ = ["VisionModelZoo", "VisionTransformer", "CrossEntropyLoss", "FusedSGD", "FusedAdamW", "GraphedStep", "ClassifierHead", "load_reference_checkpoint", "RunLog", "VitmiError"]

@@ -9,8 +9,9 @@
     correct = (argmax(outputs) == labels)           :85-95
     loss.item()                                     :452
 
-Logging/progress (utils_stats.py) is out of scope; `run_one_epoch` returns the per-batch
-losses and the per-sample correct flags the reference feeds to its Stats object.  Unlike
+`run_one_epoch` returns the per-batch losses and the per-sample correct flags the reference
+feeds to its Stats object; `fit(log=RunLog(...))` writes them in the reference's JSON schema
+(vit_torch_amd.stats; the progress bars of utils_stats.py are out of scope).  Unlike
 the reference's two device->host syncs per step, loss and correct count stay on the device
 and are read once per epoch.
 """
@@ -160,13 +161,27 @@ class Network:
         return {"loss": loss_values, "loss_avg": float(np.mean(loss_values)) if loss_values else math.nan,
                 "correct": correct, "acc": float(correct.mean()) if correct.size else math.nan}
 
-    def fit(self, train_loader, val_loader=None, epochs: Optional[int] = None):
+    def fit(self, train_loader, val_loader=None, epochs: Optional[int] = None, log=None, verbose=False):
+        """`log`: a vit_torch_amd.stats.RunLog; gets one entry per split and epoch (train with
+        the epoch's LR, val with lr 0.0 as in the reference's files) and is saved after each."""
         history = []
         for epoch in range(epochs if epochs is not None else self.epochs):
-            rec = {"epoch": epoch, "lr": self.optimizer.param_groups[0]["lr"],
-                   "train": self.run_one_epoch(train_loader, training=True)}
-            self.lr_scheduler.step()                                       # utils_network.py:311-313
-            if val_loader is not None:
-                rec["val"] = self.run_one_epoch(val_loader, training=False)
+            lr = self.optimizer.param_groups[0]["lr"]
+            rec = {"epoch": epoch, "lr": lr}
+            for split, loader in (("train", train_loader), ("val", val_loader)):
+                if loader is None:
+                    continue
+                if log is not None:
+                    log.new_round(split)
+                r = rec[split] = self.run_one_epoch(loader, training=(split == "train"))
+                if split == "train":
+                    self.lr_scheduler.step()                               # utils_network.py:311-313
+                if log is not None:
+                    log.finish_round(split, epoch=epoch, lr=lr if split == "train" else 0.0, loss=r["loss_avg"],
+                                     acc=r["acc"], sample=int(r["correct"].size))
+                    if verbose:
+                        print(log.console_line(split), flush=True)
             history.append(rec)
+        if log is not None:
+            log.finish()
         return history
