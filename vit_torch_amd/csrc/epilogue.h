@@ -24,6 +24,7 @@ struct GemmArgs {
   const void* B; int64_t ldb; int b_km;
   void* ws; size_t ws_bytes;      // optional scratch (split-K partial tiles)
   unsigned long long* dbg;        // diagnostic phase stamps (NULL in production)
+  int dbg_blocks;                 // workgroups whose timeline is stamped
   int64_t batch, batch_inner, a_bs[2], b_bs[2], c_bs[2];   // batched form (generic kernel)
   int vec_a, vec_b;               // operand rows are 16-B aligned: vector staging allowed
   EpiArgs e;

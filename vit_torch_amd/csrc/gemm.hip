@@ -14,7 +14,10 @@ size_t gemm_fast_workspace(const GemmArgs& g);
 // diagnostic only (tools/gemm_phases.py): block 0 of the PIPE=1 kernel accumulates
 // s_memtime stamps of its R / M phases and barrier waits into this buffer
 static unsigned long long* g_gemm_dbg = nullptr;
-extern "C" void vitmi_debug_gemm_stamps(unsigned long long* buf) { g_gemm_dbg = buf; }
+static int g_gemm_dbg_blocks = 64;
+extern "C" void vitmi_debug_gemm_stamps(unsigned long long* buf) { g_gemm_dbg = buf; g_gemm_dbg_blocks = 64; }
+// timeline of the first `blocks` workgroups: buf holds 64 + 4 * blocks entries
+extern "C" void vitmi_debug_gemm_timeline(unsigned long long* buf, int blocks) { g_gemm_dbg = buf; g_gemm_dbg_blocks = blocks; }
 
 namespace {
 
@@ -156,6 +159,7 @@ static int build_args(const vitmi_gemm_desc* d, GemmArgs* out) {
   g.B = d->B; g.ldb = d->ldb; g.b_km = d->b_kmajor ? 1 : 0;
   g.ws = d->workspace; g.ws_bytes = d->workspace_bytes;
   g.dbg = g_gemm_dbg;
+  g.dbg_blocks = g_gemm_dbg_blocks;
   g.batch = d->batch > 1 ? d->batch : 1;
   g.batch_inner = d->batch_inner > 0 ? d->batch_inner : 1;
   for (int i = 0; i < 2; ++i) { g.a_bs[i] = d->a_bs[i]; g.b_bs[i] = d->b_bs[i]; g.c_bs[i] = d->c_bs[i]; }

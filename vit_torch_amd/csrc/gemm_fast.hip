@@ -249,7 +249,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
   const int nt = SPLITK ? min(ksps, nt_all - kt0) : nt_all;
   // diagnostic build of the timeline (armed by tools/gemm_phases.py only): entry,
   // epilogue start and end of the first 64 blocks, wave 0
-  const bool dbg_tl = g.dbg != nullptr && blockIdx.x < 64 && wave == 0;
+  const bool dbg_tl = g.dbg != nullptr && (int)blockIdx.x < g.dbg_blocks && wave == 0;
   unsigned long long tl0 = 0;
   if (dbg_tl) tl0 = stamp();
   if constexpr (PIPE == 0) {
@@ -463,14 +463,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
     for (int i = 0; i < W; ++i) { sx[0][j][i] = 0.f; sx[1][j][i] = 0.f; }
   if (side) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) epi_side<MODE, TC, W>(g.e, m0 + wm * 128 + j * RPI + rr, ncol, sx[0][j]);
+    for (int j = 0; j < NJ; ++j) epi_side<MODE, TC, W>(g.e, m0 + wm * 128 + j * RPI, rr, ncol, sx[0][j]);
   }
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi) {
     if (side && mi + 1 < 8) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
-        epi_side<MODE, TC, W>(g.e, m0 + wm * 128 + (mi + 1) * 16 + j * RPI + rr, ncol, sx[(mi + 1) & 1][j]);
+        epi_side<MODE, TC, W>(g.e, m0 + wm * 128 + (mi + 1) * 16 + j * RPI, rr, ncol, sx[(mi + 1) & 1][j]);
     }
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
@@ -484,11 +484,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
         const f32x4 t4 = *reinterpret_cast<const f32x4*>(tr + row * TRS + rc + 4 * qq);
         v[4 * qq] = t4[0]; v[4 * qq + 1] = t4[1]; v[4 * qq + 2] = t4[2]; v[4 * qq + 3] = t4[3];
       }
-      const int64_t m = m0 + wm * 128 + mi * 16 + row;
       if constexpr (SPLITK)
-        storev<float, W>(ws + ((int64_t)split * g.M + m) * g.N + ncol, v);
+        storev<float, W>(ws + row_off((int64_t)split * g.M + m0 + wm * 128 + mi * 16 + j * RPI, rr, g.N, ncol), v);
       else {
-        epi_row<MODE, TC, W>(g.e, m, ncol, v, bias_r, gamma_r, sx[mi & 1][j]);
+        epi_row<MODE, TC, W>(g.e, m0 + wm * 128 + mi * 16 + j * RPI, rr, ncol, v, bias_r, gamma_r, sx[mi & 1][j]);
         if constexpr (MODE == VITMI_EPI_DGELU) {
 #pragma unroll
           for (int i = 0; i < W; ++i) cs[i] += v[i];
@@ -514,6 +513,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
     if (lane == 0) {
       g.dbg[64 + blockIdx.x * 4 + 0] = tl0; g.dbg[64 + blockIdx.x * 4 + 1] = tl1;
       g.dbg[64 + blockIdx.x * 4 + 2] = tl2;
+      unsigned long long rt;                       // 100 MHz wall clock: relates cycles to time
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt) :: "memory");
+      g.dbg[64 + blockIdx.x * 4 + 3] = rt;
     }
   }
 }

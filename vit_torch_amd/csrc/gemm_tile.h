@@ -64,19 +64,45 @@ __device__ __forceinline__ void raw_barrier() {
 }
 
 
-// ---- fast GELU for the bf16 epilogues: erf by Abramowitz-Stegun 7.1.26
-// (|abs err| <= 1.5e-7, far below bf16 resolution); ONE exp serves both the erf
-// tail and the Gaussian pdf, so gelu' costs no second transcendental.  The fp32
-// parity mode (generic kernel) keeps erff.
-__device__ __forceinline__ void gelu_parts(float x, float* cdf, float* pdf) {
-  const float ax = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * ax);
-  const float ex = __expf(-ax * ax);                      // exp(-x^2/2)
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f +
-                     t * (-1.453152027f + t * 1.061405429f))));
-  const float erf_abs = 1.f - poly * ex;
-  *cdf = 0.5f * (1.f + copysignf(erf_abs, x));
-  *pdf = 0.39894228040143267794f * ex;
+// ---- fast GELU for the bf16 epilogues, two elements at a time so that the polynomial
+// runs on v_pk_fma_f32 / v_pk_mul_f32 (the GELU / gelu' epilogues are VALU-issue bound).
+// erfc by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below bf16 resolution):
+//   h(x) = Phi(-|x|) = 0.5 erfc(|x| / sqrt 2) = e * t (b1 + t (b2 + ... t b5)),
+//   t = 1 / (1 + 0.3275911 |x| / sqrt 2),  e = exp(-x^2 / 2) = exp2(x^2 * -0.5 log2 e),
+// with b_i = a_i / 2.  ONE exp serves the tail and the Gaussian pdf, so gelu' costs no
+// second transcendental.  Then
+//   gelu(x)  = relu(x) - |x| h              (x >= 0: x (1 - h);  x < 0: x h)
+//   gelu'(x) = 0.5 + copysign(0.5 - h, x) + x e / sqrt(2 pi).
+// The fp32 parity mode (generic kernel) keeps erff.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_tail2(f32x2 x, f32x2* h, f32x2* e) {
+  const f32x2 arg = (x * x) * -0.72134752044f;
+  f32x2 ee, t;
+  ee[0] = __builtin_amdgcn_exp2f(arg[0]);
+  ee[1] = __builtin_amdgcn_exp2f(arg[1]);
+  t[0] = __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_fabsf(x[0]), 0.2316419f, 1.f));
+  t[1] = __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_fabsf(x[1]), 0.2316419f, 1.f));
+  f32x2 p = t * 0.5307027145f + -0.7265760135f;
+  p = p * t + 0.7107068705f;
+  p = p * t + -0.142248368f;
+  p = p * t + 0.127414796f;
+  *h = (p * t) * ee;
+  *e = ee;
+}
+__device__ __forceinline__ f32x2 gelu2(f32x2 x) {
+  f32x2 h, e, r;
+  gelu_tail2(x, &h, &e);
+  r[0] = __builtin_fmaf(-__builtin_fabsf(x[0]), h[0], __builtin_fmaxf(x[0], 0.f));
+  r[1] = __builtin_fmaf(-__builtin_fabsf(x[1]), h[1], __builtin_fmaxf(x[1], 0.f));
+  return r;
+}
+__device__ __forceinline__ f32x2 dgelu2(f32x2 x) {
+  f32x2 h, e;
+  gelu_tail2(x, &h, &e);
+  f32x2 d = 0.5f - h;
+  d[0] = __builtin_copysignf(d[0], x[0]);
+  d[1] = __builtin_copysignf(d[1], x[1]);
+  return (d + 0.5f) + (x * e) * 0.39894228040143267794f;
 }
 
 // ---- W-wide row vectors (W = 8 for bf16 outputs = 16 B, W = 4 for fp32 = 16 B)
@@ -124,17 +150,29 @@ __device__ __forceinline__ bool epi_has_side(const EpiArgs& e) {
 }
 // load it for W columns of row m: issued a whole strip ahead of its use, so the HBM
 // latency of the 128-512 KiB a tile reads here is not paid row by row
+// The row index comes in two parts, m = mu + ml: `mu` wave-uniform (tile / strip / row
+// group), `ml` the lane's row within the group.  mu * ld is then scalar arithmetic and
+// ml * ld + n is the same for every row a lane handles, so a row costs one 64-bit add
+// instead of a 64-bit vector multiply per array (those were 13 % of the GELU epilogue).
+__device__ __forceinline__ int64_t row_off(int64_t mu, int64_t ml, int64_t ld, int64_t n) {
+  return mu * ld + (ml * ld + n);
+}
+template <int MODE, typename TC, int W>
+__device__ __forceinline__ void epi_side(const EpiArgs& e, int64_t mu, int64_t ml, int64_t n, float (&x)[W]) {
+  if constexpr (MODE == VITMI_EPI_RESIDUAL) loadv<TC, W>(reinterpret_cast<const TC*>(e.R) + row_off(mu, ml, e.ldr, n), x);
+  else if constexpr (MODE == VITMI_EPI_DGELU) loadv<bf16, W>(reinterpret_cast<const bf16*>(e.AUX) + row_off(mu, ml, e.ldaux, n), x);
+  else if constexpr (MODE == VITMI_EPI_STORE && sizeof(TC) == 4) loadv<float, W>(reinterpret_cast<const float*>(e.C) + row_off(mu, ml, e.ldc, n), x);
+}
 template <int MODE, typename TC, int W>
 __device__ __forceinline__ void epi_side(const EpiArgs& e, int64_t m, int64_t n, float (&x)[W]) {
-  if constexpr (MODE == VITMI_EPI_RESIDUAL) loadv<TC, W>(reinterpret_cast<const TC*>(e.R) + m * e.ldr + n, x);
-  else if constexpr (MODE == VITMI_EPI_DGELU) loadv<bf16, W>(reinterpret_cast<const bf16*>(e.AUX) + m * e.ldaux + n, x);
-  else if constexpr (MODE == VITMI_EPI_STORE && sizeof(TC) == 4) loadv<float, W>(reinterpret_cast<const float*>(e.C) + m * e.ldc + n, x);
+  epi_side<MODE, TC, W>(e, 0, m, n, x);
 }
 
 template <int MODE, typename TC, int W>
-__device__ __forceinline__ void epi_row(const EpiArgs& e, int64_t m, int64_t n, float (&v)[W],
+__device__ __forceinline__ void epi_row(const EpiArgs& e, int64_t mu, int64_t ml, int64_t n, float (&v)[W],
                                         const float (&b)[W], const float (&gm)[W], const float (&x)[W]) {
   TC* C = reinterpret_cast<TC*>(e.C);
+  const int64_t m = mu + ml;
   if constexpr (MODE == VITMI_EPI_STORE) {
 #pragma unroll
     for (int i = 0; i < W; ++i) v[i] = v[i] * e.alpha + b[i];
@@ -147,20 +185,20 @@ __device__ __forceinline__ void epi_row(const EpiArgs& e, int64_t m, int64_t n, 
   } else if constexpr (MODE == VITMI_EPI_BIAS_GELU) {
     float pre[W];
 #pragma unroll
-    for (int i = 0; i < W; ++i) {
-      pre[i] = v[i] + b[i];
-      if constexpr (sizeof(TC) == 2) pre[i] = (float)(bf16)pre[i];
-      float cdf, pdf;
-      gelu_parts(pre[i], &cdf, &pdf);
-      v[i] = pre[i] * cdf;
+    for (int i = 0; i < W; i += 2) {
+      f32x2 p = {v[i] + b[i], v[i + 1] + b[i + 1]};
+      if constexpr (sizeof(TC) == 2) { p[0] = (float)(bf16)p[0]; p[1] = (float)(bf16)p[1]; }
+      const f32x2 r = gelu2(p);
+      pre[i] = p[0]; pre[i + 1] = p[1];
+      v[i] = r[0]; v[i + 1] = r[1];
     }
-    if (e.C2) storev<TC, W>(reinterpret_cast<TC*>(e.C2) + m * e.ldc2 + n, pre);
+    if (e.C2) storev<TC, W>(reinterpret_cast<TC*>(e.C2) + row_off(mu, ml, e.ldc2, n), pre);
   } else if constexpr (MODE == VITMI_EPI_RESIDUAL) {
     if (e.C2) {                              // un-scaled branch output, operand dtype (bf16 here)
       float f[W];
 #pragma unroll
       for (int i = 0; i < W; ++i) f[i] = v[i] + b[i];
-      storev<bf16, W>(reinterpret_cast<bf16*>(e.C2) + m * e.ldc2 + n, f);
+      storev<bf16, W>(reinterpret_cast<bf16*>(e.C2) + row_off(mu, ml, e.ldc2, n), f);
     }
     float rs = 1.f;
     if (e.rowscale) rs = e.rowscale[(uint32_t)m / (uint32_t)e.rpg];      // uniform branch; M < 2^32
@@ -168,10 +206,9 @@ __device__ __forceinline__ void epi_row(const EpiArgs& e, int64_t m, int64_t n, 
     for (int i = 0; i < W; ++i) v[i] = x[i] + rs * gm[i] * (v[i] + b[i]);
   } else if constexpr (MODE == VITMI_EPI_DGELU) {
 #pragma unroll
-    for (int i = 0; i < W; ++i) {
-      float cdf, pdf;
-      gelu_parts(x[i], &cdf, &pdf);
-      v[i] *= cdf + x[i] * pdf;
+    for (int i = 0; i < W; i += 2) {
+      const f32x2 d = dgelu2(f32x2{x[i], x[i + 1]});
+      v[i] *= d[0]; v[i + 1] *= d[1];
     }
   } else {  // PATCH_POS
     const int64_t t = m % e.n_tok;
@@ -187,7 +224,12 @@ __device__ __forceinline__ void epi_row(const EpiArgs& e, int64_t m, int64_t n, 
       for (int i = 0; i < W; ++i) v[i] = v[i] + b[i] + ps[i];
     }
   }
-  storev<TC, W>(C + m * e.ldc + n, v);
+  storev<TC, W>(C + row_off(mu, ml, e.ldc, n), v);
+}
+template <int MODE, typename TC, int W>
+__device__ __forceinline__ void epi_row(const EpiArgs& e, int64_t m, int64_t n, float (&v)[W],
+                                        const float (&b)[W], const float (&gm)[W], const float (&x)[W]) {
+  epi_row<MODE, TC, W>(e, 0, m, n, v, b, gm, x);
 }
 
 constexpr int TRS = 68;                       // floats per row of the transpose strip (64 + pad)
