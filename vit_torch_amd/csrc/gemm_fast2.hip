@@ -299,21 +299,49 @@ __global__ __launch_bounds__(NT2, 2) void gemm_fast2_kernel(GemmArgs g, int tile
   colsum_part2<MODE, SPLITK, W, LPR>(g, cs, m0, wm, ncol, col_ok, rr);
 }
 
-__global__ void splitk_reduce2_kernel(const float* __restrict__ ws, int splits, EpiArgs e, int64_t M, int64_t N) {
+// C = epilogue(sum_s ws[s]).  A small output with many slices (Swin stage 1: 96 x 384 from
+// 256 slices) would leave a one-thread-per-output kernel with 36 workgroups walking 256
+// dependent-latency loads each, so the slices of one output are spread over the P waves of a
+// workgroup (wave p sums s = p, p + P, ...; lane = output, so every load is a full 1-KiB
+// row piece) and wave 0 adds the P partial sums in a fixed order: deterministic for a shape.
+__global__ __launch_bounds__(1024) void splitk_reduce2_kernel(const float* __restrict__ ws, int splits, EpiArgs e,
+                                                             int64_t M, int64_t N) {
+  __shared__ f32x4 part[15 * 64];
+  const int lane = threadIdx.x & 63;
+  const int p = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), P = blockDim.x >> 6;
   const int64_t n4 = N / 4;
-  const int64_t total = M * n4;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t m = i / n4, n = (i % n4) * 4;
-    f32x4 acc = *reinterpret_cast<const f32x4*>(ws + m * N + n);
-    for (int s = 1; s < splits; ++s) acc += *reinterpret_cast<const f32x4*>(ws + ((int64_t)s * M + m) * N + n);
-    float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-    float b[4] = {0.f, 0.f, 0.f, 0.f};
-    const float one[4] = {1.f, 1.f, 1.f, 1.f};
-    if (e.bias) loadv<float, 4>(e.bias + n, b);
-    float x[4] = {0.f, 0.f, 0.f, 0.f};
-    if (e.accumulate) epi_side<VITMI_EPI_STORE, float, 4>(e, m, n, x);
-    epi_row<VITMI_EPI_STORE, float, 4>(e, m, n, v, b, one, x);
+  const int64_t total = M * n4, slab = M * N;
+  for (int64_t base = (int64_t)blockIdx.x * 64; base < total; base += (int64_t)gridDim.x * 64) {   // workgroup-uniform
+    const int64_t i = base + lane;
+    const bool ok = i < total;
+    const float* src = ws + (ok ? i : total - 1) * 4;            // clamped: no branch around the loads
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int s = p; s < splits; s += P) acc += *reinterpret_cast<const f32x4*>(src + (int64_t)s * slab);
+    if (P > 1) {
+      if (p > 0) part[(p - 1) * 64 + lane] = acc;
+      __syncthreads();
+    }
+    if (p == 0 && ok) {
+      for (int q = 1; q < P; ++q) acc += part[(q - 1) * 64 + lane];
+      const int64_t m = i / n4, n = (i % n4) * 4;
+      float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+      float b[4] = {0.f, 0.f, 0.f, 0.f};
+      const float one[4] = {1.f, 1.f, 1.f, 1.f};
+      if (e.bias) loadv<float, 4>(e.bias + n, b);
+      float x[4] = {0.f, 0.f, 0.f, 0.f};
+      if (e.accumulate) epi_side<VITMI_EPI_STORE, float, 4>(e, m, n, x);
+      epi_row<VITMI_EPI_STORE, float, 4>(e, m, n, v, b, one, x);
+    }
+    if (P > 1) __syncthreads();
   }
+}
+// waves per output group: enough waves to fill the chip, at least two slices per wave
+inline int splitk_reduce2_waves(int64_t total4, int splits) {
+  const int64_t groups = (total4 + 63) / 64;
+  int P = 1;
+  while (P < 16 && groups * P < 2048 && 2 * (2 * P) <= splits) P *= 2;
+  return P;
 }
 
 // 512 resident workgroups (2 per CU): split the contraction when the output has fewer tiles
@@ -348,9 +376,11 @@ int launch2(const GemmArgs& g, hipStream_t stream) {
       hipLaunchKernelGGL(kern, dim3(nwg * splits), dim3(NT2), LDS2, stream, g, tiles_n, nwg * splits, nwg, ksps, ws);
       int rc = vitmi_check_launch("gemm_fast2_kernel(split-K)");
       if (rc) return rc;
-      int64_t blocks = (g.M * g.N / 4 + 255) / 256;
-      if (blocks > 2048) blocks = 2048;
-      hipLaunchKernelGGL(splitk_reduce2_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, ws, splits, g.e, g.M, g.N);
+      const int64_t total4 = g.M * g.N / 4;
+      const int P = splitk_reduce2_waves(total4, splits);
+      int64_t blocks = (total4 + 63) / 64;
+      if (blocks > 8192) blocks = 8192;
+      hipLaunchKernelGGL(splitk_reduce2_kernel, dim3((unsigned)blocks), dim3(64 * P), 0, stream, ws, splits, g.e, g.M, g.N);
       return vitmi_check_launch("splitk_reduce2_kernel");
     }
   }
