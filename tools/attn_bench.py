@@ -43,12 +43,15 @@ for spec in specs:
     raw.vitmi_debug_attn_bwd(1)
     buf = torch.zeros(64 * 8, dtype=torch.int64, device="cuda")
     raw.vitmi_debug_attn_stamps.argtypes = [ctypes.c_void_p]
-    raw.vitmi_debug_attn_stamps(buf.data_ptr())
-    ops.attn_bwd(qkv, O, do, lse, dqkv, B, N, H, hd, scale, dbias_part=part)
-    torch.cuda.synchronize()
-    raw.vitmi_debug_attn_stamps(None)
-    t = buf.cpu().view(64, 8)[:, :5]
-    d = (t[:, 1:] - t[:, :-1]).float()
-    print("   fused timeline, median cycles over 64 workgroups: stage %d, K frags + zero dQ %d, loop %d, stores + bias sums %d" %
-          tuple(d.median(0).values.tolist()))
+    for rnd in range(2):
+        for st in (0,):
+            tb = timed(lambda: ops.attn_bwd(qkv, O, do, lse, dqkv, B, N, H, hd, scale, dbias_part=part))
+            raw.vitmi_debug_attn_stamps(buf.data_ptr())
+            ops.attn_bwd(qkv, O, do, lse, dqkv, B, N, H, hd, scale, dbias_part=part)
+            torch.cuda.synchronize()
+            raw.vitmi_debug_attn_stamps(None)
+            t = buf.cpu().view(64, 8)[:, :5]
+            d = (t[:, 1:] - t[:, :-1]).float()
+            print("   fused %7.1f us; median cycles over 64 mid-launch workgroups: stage %d, K frags + zero dQ %d, "
+                  "loop %d, stores + bias sums %d" % ((tb,) + tuple(d.median(0).values.tolist())))
     raw.vitmi_debug_attn_bwd(-1)

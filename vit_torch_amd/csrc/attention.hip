@@ -730,6 +730,10 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16* __restr
     o8[i] = *reinterpret_cast<const bf16x8*>(ob + (int64_t)row * os + pc * 8);
     lv[i] = lse[(int64_t)bh * N + row];           // with the batch: a load in the store loop would drain it each time
   }
+  // hipcc sinks a load whose only use sits under `if (pc == 0)` into that branch, behind the
+  // wait for the batch: a second HBM round trip.  An opaque use keeps all of them up here.
+#pragma unroll
+  for (int i = 0; i < IT; ++i) asm volatile("" : "+v"(lv[i]));
 #pragma unroll
   for (int i = 0; i < IT; ++i) {
     const int c = tid + i * nthr, row = c / CPR, pc = c % CPR;
@@ -997,6 +1001,7 @@ extern "C" size_t vitmi_attn_bwd_workspace(int64_t B, int64_t N, int64_t H) {
 }
 
 static unsigned long long* g_attn_dbg = nullptr;
+
 extern "C" void vitmi_debug_attn_stamps(void* p) { g_attn_dbg = reinterpret_cast<unsigned long long*>(p); }
 static int g_attn_bwd_mode = -1;     // diagnostic / test hook: 0 = dkdv + dq kernels, 1 = fused where possible
 extern "C" void vitmi_debug_attn_bwd(int mode) { g_attn_bwd_mode = mode; }
