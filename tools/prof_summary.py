@@ -1,8 +1,14 @@
 """Summarise a rocprofv3 --kernel-trace --stats run: per-kernel totals per step."""
 import csv, glob, re, sys
 d = sys.argv[1]; steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
-f = glob.glob(d + "/**/*kernel_stats.csv", recursive=True)[0]
+f = d if d.endswith(".csv") else glob.glob(d + "/**/*kernel_stats.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
+# the steps actually executed (graph trial steps, capture warm-ups and the instrumented step
+# included) = launches of a once-per-step kernel, when the trace holds one
+for r in rows:
+    if re.search(r"xent_kernel\(|xent_kernel[A-Z]", r["Name"]) and "reduce" not in r["Name"]:
+        steps = float(r["Calls"])
+        break
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print(f"total kernel time {tot/1e6:.2f} ms over {steps:g} steps = {tot/1e6/steps:.2f} ms/step")
 print(f"{'ms/step':>9} {'calls/step':>10} {'avg us':>9} {'%':>6}  kernel")
