@@ -28,11 +28,22 @@ template <typename T> __device__ __forceinline__ float ldf(const T* p) { return 
 __device__ __forceinline__ float th_wlane(float v, int idx) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), idx));
 }
+// The holder VGPR keeps the matrix in the PADDED 8 x 8 layout (lane 8a + c = W[a][c], zero
+// outside H x H), so every readlane has a compile-time lane and no branch on H.
+__device__ __forceinline__ float th_wholder(const float* W, int lane, int H) {
+  const int a = lane >> 3, c = lane & 7;
+  const float v = W[min(a, H - 1) * H + min(c, H - 1)];        // unconditional, clamped
+  return (a < H && c < H) ? v : 0.f;
+}
+__device__ __forceinline__ float th_bholder(const float* b, int lane, int H) {
+  const float v = b[min(lane, H - 1)];
+  return lane < H ? v : 0.f;
+}
 #define TH_LOAD_W(dst, src_vgpr, H_)                                                    \
   float dst[TH_MAXH][TH_MAXH];                                                          \
   _Pragma("unroll") for (int a_ = 0; a_ < TH_MAXH; ++a_)                                \
     _Pragma("unroll") for (int c_ = 0; c_ < TH_MAXH; ++c_)                              \
-      dst[a_][c_] = (a_ < (H_) && c_ < (H_)) ? th_wlane(src_vgpr, a_ * (H_) + c_) : 0.f
+      dst[a_][c_] = th_wlane(src_vgpr, a_ * TH_MAXH + c_)
 
 template <bool VEC> __device__ __forceinline__ int th_key(int lane, int c) { return VEC ? lane * 4 + c : c * 64 + lane; }
 
@@ -96,12 +107,14 @@ __global__ __launch_bounds__(256) void th_softmax_fwd_kernel(const T* __restrict
                                                             T* __restrict__ Pm, int64_t rows /*B*N*/, int H, int N,
                                                             int Nk, int ld) {
   static_assert(TH_MAXC == 4, "a lane owns four keys");
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t row = (int64_t)blockIdx.x * 4 + w;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t row = (int64_t)blockIdx.x * 4 + w;          // wave-uniform: the row arithmetic stays scalar
   if (row >= rows) return;
   const int64_t b = row / N, i = row % N;
-  const float wl_v = lane < H * H ? Wl[lane] : 0.f, ww_v = lane < H * H ? Ww[lane] : 0.f;
-  const float bl_v = lane < H ? bl[lane] : 0.f, bw_v = lane < H ? bw[lane] : 0.f;
+  const float wl_v = th_wholder(Wl, lane, H), ww_v = th_wholder(Ww, lane, H);
+  const float bl_v = th_bholder(bl, lane, H), bw_v = th_bholder(bw, lane, H);
+  // bf16 scores: hardware exp2 / rcp (P is stored in bf16); the fp32 parity form keeps expf and /
+  constexpr bool FAST = sizeof(T) == 2;
   float s[TH_MAXH][TH_MAXC], p[TH_MAXH][TH_MAXC];
 #pragma unroll
   for (int h = 0; h < TH_MAXH; ++h) {
@@ -110,9 +123,12 @@ __global__ __launch_bounds__(256) void th_softmax_fwd_kernel(const T* __restrict
     for (int c = 0; c < TH_MAXC; ++c) s[h][c] = k.get(c);
   }
   TH_LOAD_W(wl, wl_v, H);
+  // All TH_MAXH heads go through the same straight-line code (rows of Wl / Ww beyond H are
+  // zero, so a surplus head is a softmax of zeros that nothing reads): with a `break` at H
+  // the eight dependent reduction chains ran one after the other behind branches; like this
+  // the scheduler interleaves them.  Only the stores are guarded.
 #pragma unroll
   for (int hp = 0; hp < TH_MAXH; ++hp) {
-    if (hp >= H) break;
     const float blh = th_wlane(bl_v, hp);
     float v[TH_MAXC], mx = -INFINITY;
 #pragma unroll
@@ -123,28 +139,25 @@ __global__ __launch_bounds__(256) void th_softmax_fwd_kernel(const T* __restrict
       v[c] = (th_key<VEC>(lane, c) < Nk) ? a : -INFINITY;
       mx = fmaxf(mx, v[c]);
     }
-    mx = wave_max(mx);
+    mx = wave_max_dpp(mx);
     float sum = 0.f;
 #pragma unroll
-    for (int c = 0; c < TH_MAXC; ++c) { v[c] = expf(v[c] - mx); sum += v[c]; }
-    sum = wave_sum(sum);
-    const float inv = 1.f / sum;
+    for (int c = 0; c < TH_MAXC; ++c) {
+      v[c] = FAST ? __builtin_amdgcn_exp2f((v[c] - mx) * 1.4426950408889634f) : expf(v[c] - mx);
+      sum += v[c];
+    }
+    sum = wave_sum_dpp(sum);
+    const float inv = FAST ? __builtin_amdgcn_rcpf(sum) : 1.f / sum;
     Keep4<T> o;
 #pragma unroll
     for (int c = 0; c < TH_MAXC; ++c) {
       o.set(c, v[c] * inv);
       p[hp][c] = o.get(c);                          // backward differentiates at the STORED probabilities
     }
-    th_store<T, VEC>(P + ((b * H + hp) * N + i) * ld, lane, Nk, o);
+    if (hp < H) th_store<T, VEC>(P + ((b * H + hp) * N + i) * ld, lane, Nk, o);
   }
+  __builtin_amdgcn_sched_barrier(0);                // Wl's 64 scalars are dead before Ww's are fetched
   TH_LOAD_W(ww, ww_v, H);
-#pragma unroll
-  for (int hp = 0; hp < TH_MAXH; ++hp) {            // heads >= H: p was never written
-    if (hp >= H) {
-#pragma unroll
-      for (int c = 0; c < TH_MAXC; ++c) p[hp][c] = 0.f;
-    }
-  }
 #pragma unroll
   for (int ho = 0; ho < TH_MAXH; ++ho) {
     if (ho >= H) break;
@@ -169,8 +182,8 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const T* __restrict
                                                             const float* __restrict__ Ww, T* __restrict__ dS,
                                                             float* __restrict__ part, int64_t rows, int H, int N,
                                                             int Nk, int ld) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const float wl_v = lane < H * H ? Wl[lane] : 0.f, ww_v = lane < H * H ? Ww[lane] : 0.f;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const float wl_v = th_wholder(Wl, lane, H), ww_v = th_wholder(Ww, lane, H);
   float aWl[TH_MAXH][TH_MAXH], aWw[TH_MAXH][TH_MAXH], abl[TH_MAXH], abw[TH_MAXH];
 #pragma unroll
   for (int a = 0; a < TH_MAXH; ++a) {
@@ -219,7 +232,7 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const T* __restrict
       }
     }
 #pragma unroll
-    for (int hp = 0; hp < TH_MAXH; ++hp) dot[hp] = wave_sum(dot[hp]);
+    for (int hp = 0; hp < TH_MAXH; ++hp) dot[hp] = wave_sum_dpp(dot[hp]);
     {
       Keep4<T> pk[TH_MAXH], sk[TH_MAXH], ok[TH_MAXH];
 #pragma unroll

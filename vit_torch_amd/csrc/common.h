@@ -54,6 +54,34 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// The same reductions on the DPP network (no LDS crossbar): quad swaps, the two row mirrors,
+// then row_bcast:15 / row_bcast:31 carry the row totals up to lane 63, which v_readlane
+// hands to every lane as a scalar.  Six dependent VALU instructions instead of six
+// ds_bpermute round trips (~100 cycles each): for kernels that reduce many short rows.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_take(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                               CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += dpp_take<0xB1, 0xf>(0.f, v);        // quad_perm [1,0,3,2]
+  v += dpp_take<0x4E, 0xf>(0.f, v);        // quad_perm [2,3,0,1]
+  v += dpp_take<0x141, 0xf>(0.f, v);       // row_half_mirror
+  v += dpp_take<0x140, 0xf>(0.f, v);       // row_mirror: every lane holds its row's total
+  v += dpp_take<0x142, 0xa>(0.f, v);       // row_bcast:15 into rows 1 and 3
+  v += dpp_take<0x143, 0xc>(0.f, v);       // row_bcast:31 into rows 2 and 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  v = fmaxf(v, dpp_take<0xB1, 0xf>(-INFINITY, v));
+  v = fmaxf(v, dpp_take<0x4E, 0xf>(-INFINITY, v));
+  v = fmaxf(v, dpp_take<0x141, 0xf>(-INFINITY, v));
+  v = fmaxf(v, dpp_take<0x140, 0xf>(-INFINITY, v));
+  v = fmaxf(v, dpp_take<0x142, 0xa>(-INFINITY, v));
+  v = fmaxf(v, dpp_take<0x143, 0xc>(-INFINITY, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 // exact (erf) GELU and its derivative, as nn.GELU() default
 __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
