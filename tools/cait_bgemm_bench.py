@@ -34,12 +34,18 @@ cases = {
                                             batch=B * H, batch_inner=H, a_bs=(H * Np * NS, Np * NS), b_bs=(Np * D3, hd),
                                             c_bs=(Np * D3, hd), c_off=D, alpha=0.1),
 }
-for name, fn in cases.items():
-    for _ in range(3):
-        fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize(); e0.record()
-    for _ in range(10):
-        fn()
-    e1.record(); torch.cuda.synchronize()
-    print(f"{name:14s} {e0.elapsed_time(e1) / 10 * 1e3:8.1f} us")
+import ctypes
+from vit_torch_amd import _lib
+raw = ctypes.CDLL(str(_lib.LIB_PATH))
+for parts in [int(v) for v in os.environ.get("PARTS", "1,2,4").split(",")]:   # workgroups per problem
+    raw.vitmi_debug_gemm_small_parts(parts)
+    for name, fn in cases.items():
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(10):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        print(f"parts {parts}: {name:14s} {e0.elapsed_time(e1) / 10 * 1e3:8.1f} us")
+raw.vitmi_debug_gemm_small_parts(0)

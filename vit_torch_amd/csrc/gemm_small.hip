@@ -113,6 +113,10 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(SmallArgs a) {
   const int M = a.M, N = a.N, K = a.K;
   const int tiles_m = (M + 15) / 16, tiles_n = (N + 15) / 16;
   const int g = lane >> 4, li = lane & 15;
+  // gridDim.y workgroups share one problem (small batches: 512 problems are two workgroups per
+  // CU, too few waves to hide the staging round trips): part p takes row tiles 4p + w, stepping
+  // by 4 * parts; every part stages the shared operand for itself (19-28 KB, from L2)
+  const int part = blockIdx.y, parts = gridDim.y;
 
   if constexpr (FORM == 0) {
     const int ksteps = (K + 31) / 32;              // <= 2 (host checks K <= 64)
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(SmallArgs a) {
     const int RSB = 64 * 2 + 16;                   // 64 k (zero beyond K) + pad: conflict-free row reads
     stage_rows(smem, RSB, B, a.ldb, 0, tiles_n * 16, N, K, 64, tid, 256);
     __syncthreads();
-    for (int rt = w; rt < tiles_m; rt += 4) {
+    for (int rt = w + 4 * part; rt < tiles_m; rt += 4 * parts) {
       const int row = min(rt * 16 + li, M - 1);
       bf16x8 af[2];
 #pragma unroll
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(SmallArgs a) {
     stage_rows(Ys, RSY, B, a.ldb, 0, Kp, K, N, Np, tid, 256);
     if constexpr (FORM == 1) {
       __syncthreads();
-      for (int rt = w; rt < tiles_m; rt += 4) {
+      for (int rt = w + 4 * part; rt < tiles_m; rt += 4 * parts) {
         const int row = min(rt * 16 + li, M - 1);
         f32x4 acc[SB_MAXN / 16];
 #pragma unroll
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(SmallArgs a) {
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < RT_MAX; ++q) {
-          const int rt = w + 4 * q;
+          const int rt = w + 4 * (part + parts * q);
           if (rt < tiles_m) {
             for (int ks = 0; ks < rows / 32; ++ks) {
               const bf16x8 af = tr_frag(Ss, RSS, ks * 32, rt * 16, lane);
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(SmallArgs a) {
       }
 #pragma unroll
       for (int q = 0; q < RT_MAX; ++q) {
-        const int rt = w + 4 * q;
+        const int rt = w + 4 * (part + parts * q);
         if (rt < tiles_m) {
 #pragma unroll
           for (int ct = 0; ct < SB_MAXN / 16; ++ct)
@@ -227,6 +231,9 @@ inline size_t small_lds(int form, int M, int N, int K) {
 }
 
 }  // namespace
+
+static int g_small_parts = 0;     // diagnostic hook: workgroups per problem, 0 = heuristic
+extern "C" void vitmi_debug_gemm_small_parts(int n) { g_small_parts = n; }
 
 // which batched bf16 problems take this kernel (plain store epilogue only)
 int gemm_small_form(const GemmArgs& g, int in_bf16) {
@@ -253,7 +260,18 @@ int gemm_small_launch(const GemmArgs& g, int form, hipStream_t stream) {
   for (int i = 0; i < 2; ++i) { a.a_bs[i] = g.a_bs[i]; a.b_bs[i] = g.b_bs[i]; a.c_bs[i] = g.c_bs[i]; }
   a.alpha = g.e.alpha;
   const size_t lds = small_lds(form, a.M, a.N, a.K);
-  const dim3 grid((unsigned)g.batch);
+  // fewer than four workgroups per CU: split the row tiles of a problem over two workgroups
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  }
+  const int tiles_m = (a.M + 15) / 16;
+  // (measured at 512 problems of 196 x 196 x 48: form 0 22.3 -> 20.3 us, form 1 22.1 -> 16.7;
+  // form 2 streams S through LDS once per workgroup, so a second one doubles that: 24.5 -> 35.9)
+  const unsigned parts = (g_small_parts > 0) ? (unsigned)g_small_parts
+                         : ((form != 2 && g.batch < 4 * (int64_t)cus && tiles_m >= 8) ? 2u : 1u);
+  const dim3 grid((unsigned)g.batch, parts);
 #define SMALL_GO(F)                                                                                   \
   do {                                                                                                \
     auto kern = gemm_small_kernel<F>;                                                                 \
