@@ -306,33 +306,39 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const T* __restrict
     v[k] += __shfl_xor(v[k], 16, 64);
     v[k] += __shfl_xor(v[k], 32, 64);
   }
-  const int stride = 2 * H * H + 2 * H;
-  float* prow = part + ((int64_t)blockIdx.x * 4 + w) * stride;
+  // the four waves of the workgroup fold through LDS (fixed order) into ONE partial row per
+  // workgroup: the row fold that follows then walks 512 rows, not 2048
+  __shared__ float wred[4][NV];
   if (lane < 16) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const int idx = base + k;                      // index in the padded layout
-      constexpr int HH = TH_MAXH * TH_MAXH;
-      if (idx < HH) {
-        const int a = idx / TH_MAXH, c = idx % TH_MAXH;
-        if (a < H && c < H) prow[a * H + c] = v[k];
-      } else if (idx < HH + TH_MAXH) {
-        const int a = idx - HH;
-        if (a < H) prow[H * H + a] = v[k];
-      } else if (idx < 2 * HH + TH_MAXH) {
-        const int a = (idx - HH - TH_MAXH) / TH_MAXH, c = (idx - HH - TH_MAXH) % TH_MAXH;
-        if (a < H && c < H) prow[H * H + H + a * H + c] = v[k];
-      } else {
-        const int a = idx - 2 * HH - TH_MAXH;
-        if (a < H) prow[2 * H * H + H + a] = v[k];
-      }
+    for (int k = 0; k < 9; ++k) wred[w][base + k] = v[k];       // index in the padded layout
+  }
+  __syncthreads();
+  const int stride = 2 * H * H + 2 * H;
+  float* prow = part + (int64_t)blockIdx.x * stride;
+  const int idx = threadIdx.x;
+  if (idx < NV) {
+    const float t = (wred[0][idx] + wred[1][idx]) + (wred[2][idx] + wred[3][idx]);
+    constexpr int HH = TH_MAXH * TH_MAXH;
+    if (idx < HH) {
+      const int a = idx / TH_MAXH, c = idx % TH_MAXH;
+      if (a < H && c < H) prow[a * H + c] = t;
+    } else if (idx < HH + TH_MAXH) {
+      const int a = idx - HH;
+      if (a < H) prow[H * H + a] = t;
+    } else if (idx < 2 * HH + TH_MAXH) {
+      const int a = (idx - HH - TH_MAXH) / TH_MAXH, c = (idx - HH - TH_MAXH) % TH_MAXH;
+      if (a < H && c < H) prow[H * H + H + a * H + c] = t;
+    } else {
+      const int a = idx - 2 * HH - TH_MAXH;
+      if (a < H) prow[2 * H * H + H + a] = t;
     }
   }
 }
 
 inline int th_bwd_blocks(int64_t rows) {
   int64_t b = (rows + 3) / 4;
-  return (int)(b < 512 ? b : 512);      // one partial row per wave: keep the fold short
+  return (int)(b < 512 ? b : 512);      // one partial row per workgroup: keep the fold short
 }
 
 // ---- class attention: one wave per (b, h); q [B, H*hd] (already scaled by the caller via
@@ -500,7 +506,7 @@ extern "C" int vitmi_th_softmax_fwd(const void* S, const float* Wl, const float*
 }
 
 extern "C" size_t vitmi_th_softmax_bwd_workspace(int64_t B, int64_t H, int64_t N) {
-  return (size_t)th_bwd_blocks(B * N) * 4 * (size_t)(2 * H * H + 2 * H) * sizeof(float);
+  return (size_t)th_bwd_blocks(B * N) * (size_t)(2 * H * H + 2 * H) * sizeof(float);
 }
 
 extern "C" int vitmi_th_softmax_bwd(const void* S, const void* P, const void* dPm, const float* Wl,
@@ -525,7 +531,7 @@ extern "C" int vitmi_th_softmax_bwd(const void* S, const void* P, const void* dP
   rc = vitmi_check_launch("th_softmax_bwd_kernel");
   if (rc) return rc;
   const int64_t stride = 2 * H * H + 2 * H;
-  const int nrows = nblk * 4;
+  const int nrows = nblk;                          // one partial row per workgroup
   float* const outs[4] = {dWl, dbl, dWw, dbw};
   const int widths[4] = {(int)(H * H), (int)H, (int)(H * H), (int)H};
   return vitmi_reduce_rows_segs(part, nrows, stride, outs, widths, stream);

@@ -110,25 +110,45 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
   }
 }
 
-// out[c] = sum_{r<S} part[r*ld + c]: 64 columns per block, the S rows split over
-// 16 waves (coalesced 256-B row segments), fixed summation order (deterministic)
+// out[c] = sum_{r<S} part[r*ld + c], fixed summation order (deterministic).
+// Column sums of S partial rows.  The partial buffers are narrow (144 .. 2304 columns) and
+// tall (256 .. 2048 rows): with 64 columns per workgroup the grid was 3 .. 36 workgroups of
+// 64 .. 128 dependent-latency loads per thread (15 .. 36 us for a few MB).  A workgroup now
+// takes FOLD_COLS columns and spreads the rows over 1024 / FOLD_COLS row groups (64-B row
+// pieces, from L2 / MALL: the producer has just written them); the groups' sums meet in LDS
+// and are added in a fixed order.
+constexpr int FOLD_COLS = 16;
+constexpr int FOLD_GROUPS = 1024 / FOLD_COLS;
+__device__ __forceinline__ float fold_rows(const float* __restrict__ part, int S, int64_t ld, int64_t col, bool ok,
+                                           float (*red)[FOLD_COLS]) {
+  const int c = threadIdx.x % FOLD_COLS, rg = threadIdx.x / FOLD_COLS;
+  float s = 0.f;
+  if (ok) {
+#pragma unroll 4
+    for (int r = rg; r < S; r += FOLD_GROUPS) s += part[(int64_t)r * ld + col];
+  }
+  red[rg][c] = s;
+  __syncthreads();
+  // 64 groups -> 4 partial sums per column (lanes 0..63 of wave 0), then a fixed 4-term sum
+  float t = 0.f;
+  if (threadIdx.x < 4 * FOLD_COLS) {
+    const int q = threadIdx.x / FOLD_COLS;
+#pragma unroll
+    for (int i = 0; i < FOLD_GROUPS / 4; ++i) t += red[q * (FOLD_GROUPS / 4) + i][c];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4 * FOLD_COLS) red[threadIdx.x / FOLD_COLS][c] = t;
+  __syncthreads();
+  return (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);     // valid in every thread of column c
+}
+
 __global__ __launch_bounds__(1024) void reduce_rows_kernel(const float* __restrict__ part, int S,
                                                            int64_t N, int64_t ld,
                                                            float* __restrict__ out) {
-  __shared__ float red[16][64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t c = (int64_t)blockIdx.x * 64 + lane;
-  float s = 0.f;
-  if (c < N)
-    for (int r = w; r < S; r += 16) s += part[(int64_t)r * ld + c];
-  red[w][lane] = s;
-  __syncthreads();
-  if (w == 0 && c < N) {
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) t += red[i][lane];
-    out[c] = t;
-  }
+  __shared__ float red[FOLD_GROUPS][FOLD_COLS];
+  const int64_t c = (int64_t)blockIdx.x * FOLD_COLS + threadIdx.x % FOLD_COLS;
+  const float t = fold_rows(part, S, ld, c, c < N, red);
+  if (threadIdx.x < FOLD_COLS && c < N) out[c] = t;
 }
 
 // the same for up to three N-wide column segments of one partial buffer, each with its own
@@ -136,22 +156,12 @@ __global__ __launch_bounds__(1024) void reduce_rows_kernel(const float* __restri
 __global__ __launch_bounds__(1024) void reduce_rows3_kernel(const float* __restrict__ part, int S,
                                                             int64_t N, int64_t ld, float* out0,
                                                             float* out1, float* out2) {
-  __shared__ float red[16][64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __shared__ float red[FOLD_GROUPS][FOLD_COLS];
   const int seg = blockIdx.y;
   float* out = seg == 0 ? out0 : (seg == 1 ? out1 : out2);
-  const int64_t c = (int64_t)blockIdx.x * 64 + lane;
-  float s = 0.f;
-  if (c < N)
-    for (int r = w; r < S; r += 16) s += part[(int64_t)r * ld + seg * N + c];
-  red[w][lane] = s;
-  __syncthreads();
-  if (w == 0 && c < N) {
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) t += red[i][lane];
-    out[c] = t;
-  }
+  const int64_t c = (int64_t)blockIdx.x * FOLD_COLS + threadIdx.x % FOLD_COLS;
+  const float t = fold_rows(part, S, ld, seg * N + c, c < N, red);
+  if (threadIdx.x < FOLD_COLS && c < N) out[c] = t;
 }
 
 // one partial buffer whose row is up to four consecutive segments of different widths, each
@@ -159,19 +169,11 @@ __global__ __launch_bounds__(1024) void reduce_rows3_kernel(const float* __restr
 struct RowSegs { float* out[4]; int end[4]; };
 __global__ __launch_bounds__(1024) void reduce_rows_segs_kernel(const float* __restrict__ part, int S,
                                                                 int64_t ld, RowSegs sg) {
-  __shared__ float red[16][64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
+  __shared__ float red[FOLD_GROUPS][FOLD_COLS];
+  const int c = blockIdx.x * FOLD_COLS + threadIdx.x % FOLD_COLS;
   const int n = sg.end[3];
-  float s = 0.f;
-  if (c < n)
-    for (int r = w; r < S; r += 16) s += part[(int64_t)r * ld + c];
-  red[w][lane] = s;
-  __syncthreads();
-  if (w == 0 && c < n) {
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) t += red[i][lane];
+  const float t = fold_rows(part, S, ld, c, c < n, red);
+  if (threadIdx.x < FOLD_COLS && c < n) {
     const int k = c < sg.end[0] ? 0 : (c < sg.end[1] ? 1 : (c < sg.end[2] ? 2 : 3));
     sg.out[k][c - (k == 0 ? 0 : sg.end[k - 1])] = t;
   }
@@ -307,7 +309,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 int vitmi_reduce_rows3(const float* part, int S, int64_t N, int64_t ld, float* out0, float* out1, float* out2,
                        hipStream_t stream) {
   const unsigned segs = out2 ? 3 : 2;
-  hipLaunchKernelGGL(reduce_rows3_kernel, dim3((unsigned)((N + 63) / 64), segs), dim3(1024), 0, stream, part, S,
+  hipLaunchKernelGGL(reduce_rows3_kernel, dim3((unsigned)((N + FOLD_COLS - 1) / FOLD_COLS), segs), dim3(1024), 0, stream, part, S,
                      N, ld, out0, out1, out2);
   return vitmi_check_launch("reduce_rows3_kernel");
 }
@@ -317,12 +319,12 @@ int vitmi_reduce_rows_segs(const float* part, int S, int64_t ld, float* const ou
   RowSegs sg;
   int e = 0;
   for (int i = 0; i < 4; ++i) { sg.out[i] = out[i]; e += width[i]; sg.end[i] = e; }
-  hipLaunchKernelGGL(reduce_rows_segs_kernel, dim3((unsigned)((e + 63) / 64)), dim3(1024), 0, stream, part, S, ld, sg);
+  hipLaunchKernelGGL(reduce_rows_segs_kernel, dim3((unsigned)((e + FOLD_COLS - 1) / FOLD_COLS)), dim3(1024), 0, stream, part, S, ld, sg);
   return vitmi_check_launch("reduce_rows_segs_kernel");
 }
 
 int vitmi_reduce_rows(const float* part, int S, int64_t N, int64_t ld, float* out, hipStream_t stream) {
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((N + 63) / 64)), dim3(1024), 0, stream, part, S, N, ld, out);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((N + FOLD_COLS - 1) / FOLD_COLS)), dim3(1024), 0, stream, part, S, N, ld, out);
   return vitmi_check_launch("reduce_rows_kernel");
 }
 
