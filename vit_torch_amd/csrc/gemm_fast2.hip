@@ -344,11 +344,17 @@ inline int splitk_reduce2_waves(int64_t total4, int splits) {
   return P;
 }
 
-// 512 resident workgroups (2 per CU): split the contraction when the output has fewer tiles
+// Split the contraction when the output has fewer tiles than the chip has CUs.  The target is
+// ONE workgroup per CU, not the two that fit: every slice writes and the reduction re-reads a
+// full fp32 output, and at the small outputs this path serves (CaiT D = 384, Swin C = 96..768
+// weight gradients) that traffic outweighs the second workgroup's latency hiding (measured,
+// whole step: target 512 / 384 / 256 / 192 / 128 -> CaiT-S24 19.74 / 19.59 / 19.37 / 19.59 /
+// 20.43 ms, Swin-T 16.33 / - / 16.05 / 16.29 / 17.04 ms).
+static int g_splitk2_target = 256;
 inline void splitk_plan2(int tiles, int nt, int* splits, int* ksps) {
   int s = 1;
   if (tiles <= 256 && nt >= 16) {
-    s = 512 / tiles;
+    s = g_splitk2_target / tiles;
     if (s > nt / 8) s = nt / 8;
     if (s < 1) s = 1;
   }
@@ -396,6 +402,9 @@ int launch2(const GemmArgs& g, hipStream_t stream) {
 }
 
 }  // namespace
+
+// diagnostic hook: workgroups a split-K launch aims at (default 256 = one per CU)
+extern "C" void vitmi_debug_gemm_splitk2_target(int n) { g_splitk2_target = n > 0 ? n : 256; }
 
 // any M, N % 8 == 0 (a lane stores 4-8 consecutive columns), K a multiple of the 32-deep slab;
 // a k-minor A ([K][M], the weight-gradient form) is staged in 8-column chunks: M % 8 == 0
