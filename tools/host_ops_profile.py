@@ -1,5 +1,7 @@
+"""Host-side op census of one eager training step (torch.profiler): which ATen ops and kernels a step launches, by count.
+usage: python tools/host_ops_profile.py <arch> <batch>"""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.argv = ["bench.py", "--arch", sys.argv[1], "--batch", sys.argv[2]]
 import bench
 from torch.profiler import profile, ProfilerActivity

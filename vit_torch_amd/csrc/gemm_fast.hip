@@ -541,10 +541,11 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, E
 }
 
 // split-K plan for a problem with `tiles` output tiles and `nt` k-steps
+static int g_splitk_target = 256;
 inline void splitk_plan(int tiles, int nt, int* splits, int* ksps) {
   int s = 1;
   if (tiles <= 128 && nt >= 16) {
-    s = 256 / tiles;
+    s = g_splitk_target / tiles;
     if (s > nt / 8) s = nt / 8;
     if (s < 1) s = 1;
   }
@@ -712,6 +713,8 @@ bool gemm_fast2_shape_ok(const GemmArgs& g);
 size_t gemm_fast2_workspace(const GemmArgs& g);
 int gemm_fast2_launch(const GemmArgs& g, hipStream_t s);
 
+// diagnostic hook: workgroups a split-K launch of the 256x256 kernel aims at (default 256)
+extern "C" void vitmi_debug_gemm_splitk_target(int n) { g_splitk_target = n > 0 ? n : 256; }
 static int g_tile_override = -1;
 // diagnostic / test hook: 1 = 256x256 tiles (one 8-wave workgroup per CU),
 // 2 = 256x128 tiles (two 4-wave workgroups per CU), -1 = default
