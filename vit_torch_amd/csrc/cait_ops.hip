@@ -174,9 +174,35 @@ __global__ __launch_bounds__(256) void th_softmax_fwd_kernel(const T* __restrict
   }
 }
 
-// ---- backward.  Per-lane accumulators of the four parameter gradients; part layout per
-// wave: [dWl H*H | dbl H | dWw H*H | dbw H] (2*H*H + 2*H floats)
-template <typename T, bool VEC>
+// ---- backward.  part layout per workgroup: [dWl H*H | dbl H | dWw H*H | dbw H].
+// The four parameter gradients are sums over every score position of an outer product of two
+// H-vectors: dWw[ho][hp] = sum dP'[ho] P[hp], dWl[hp][h] = sum dS'[hp] S[h].  Two forms:
+//  * MF (bf16, 16-B-aligned rows): they are [H x keys] x [keys x H] products, so each row's
+//    keys go through v_mfma_f32_16x16x32_bf16 — A = the 8 head rows of dP' (straight from
+//    global memory) or dS' (through a wave-private LDS tile), B = the head rows of P / S plus
+//    a row of ones whose product is the bias gradient.  Two 16x16 accumulator tiles replace
+//    144 per-lane accumulators: the kernel drops from 256 VGPRs (two waves per SIMD) and
+//    loses 512 FMAs per row and the whole cross-lane fold.
+//  * otherwise (fp32 parity mode, unaligned rows): per-lane fp32 accumulators of every
+//    element, folded at the end by a transposing butterfly.
+constexpr int TH_DSP = 2 * 64 * TH_MAXC + 16;      // pitch of a dS' tile row (bytes): 8 rows on 8 bank groups
+constexpr int TH_KSTEPS = 64 * TH_MAXC / 32;       // 32-key MFMA steps of the longest row
+__device__ __forceinline__ bf16x8 th_frag(const bf16* row, int key0, int Nk, bool head_ok) {
+  // 8 consecutive keys of one head row; keys >= Nk (pad columns may hold anything) and
+  // surplus heads read as zero.  key0 % 8 == 0 and ld % 8 == 0, so key0 < Nk stays inside the row.
+  bf16x8 v = *reinterpret_cast<const bf16x8*>(row + (key0 < Nk ? key0 : 0));
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if (!head_ok || key0 + e >= Nk) v[e] = (bf16)0.f;
+  return v;
+}
+__device__ __forceinline__ bf16x8 th_ones(int key0, int Nk) {
+  bf16x8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = key0 + e < Nk ? (bf16)1.f : (bf16)0.f;
+  return v;
+}
+template <typename T, bool VEC, bool MF>
 __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const T* __restrict__ S, const T* __restrict__ P,
                                                             const T* __restrict__ dPm, const float* __restrict__ Wl,
                                                             const float* __restrict__ Ww, T* __restrict__ dS,
@@ -184,13 +210,18 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const T* __restrict
                                                             int Nk, int ld) {
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const float wl_v = th_wholder(Wl, lane, H), ww_v = th_wholder(Ww, lane, H);
-  float aWl[TH_MAXH][TH_MAXH], aWw[TH_MAXH][TH_MAXH], abl[TH_MAXH], abw[TH_MAXH];
+  constexpr int NA = MF ? 1 : TH_MAXH;             // the per-lane accumulators exist in the FMA form only
+  float aWl[NA][NA], aWw[NA][NA], abl[NA], abw[NA];
 #pragma unroll
-  for (int a = 0; a < TH_MAXH; ++a) {
+  for (int a = 0; a < NA; ++a) {
     abl[a] = 0.f; abw[a] = 0.f;
 #pragma unroll
-    for (int c = 0; c < TH_MAXH; ++c) { aWl[a][c] = 0.f; aWw[a][c] = 0.f; }
+    for (int c = 0; c < NA; ++c) { aWl[a][c] = 0.f; aWw[a][c] = 0.f; }
   }
+  f32x4 tWw = {0.f, 0.f, 0.f, 0.f}, tWl = {0.f, 0.f, 0.f, 0.f};   // MF: D[m][n], lane = (n = lane & 15, rows 4 (lane >> 4) + r)
+  __shared__ __attribute__((aligned(16))) char dstile[MF ? 4 * TH_MAXH * TH_DSP : 16];
+  const int fi = lane & 15, fg = lane >> 4;        // fragment role: head row fi, keys 32 t + 8 fg ..
+
   // Two passes per row with the row kept COMPACT (Keep4: the 96 values of S, P, dP' for 8
   // heads would otherwise push the 144 gradient accumulators out of the register file).
   // Pass 1: dP = Ww^T dP', the softmax row dots, dWw / dbw.  Pass 2 re-reads P (L2) and S:
@@ -223,18 +254,36 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const T* __restrict
           dp[hp][c] = a;
           dot[hp] = fmaf(a, p[hp], dot[hp]);
         }
+        if constexpr (!MF) {
 #pragma unroll
-        for (int ho = 0; ho < TH_MAXH; ++ho) {
-          abw[ho] += g[ho];
+          for (int ho = 0; ho < TH_MAXH; ++ho) {
+            abw[ho] += g[ho];
 #pragma unroll
-          for (int hp = 0; hp < TH_MAXH; ++hp) aWw[ho][hp] = fmaf(g[ho], p[hp], aWw[ho][hp]);
+            for (int hp = 0; hp < TH_MAXH; ++hp) aWw[ho][hp] = fmaf(g[ho], p[hp], aWw[ho][hp]);
+          }
         }
       }
+    }
+    if constexpr (MF) {     // dWw[ho][hp] += sum_key dP'[ho][key] P[hp][key]; column 8 of B = ones -> dbw
+      // every step's loads are unconditional (a step beyond Nk loads key 0 and zeroes it):
+      // one batch of loads, not a round trip per step
+      const int64_t o = ((b * H + (fi < H ? fi : 0)) * N + i) * ld;
+      bf16x8 af[TH_KSTEPS], bf[TH_KSTEPS];
+#pragma unroll
+      for (int t = 0; t < TH_KSTEPS; ++t) {
+        const int key0 = 32 * t + 8 * fg;
+        af[t] = th_frag(reinterpret_cast<const bf16*>(dPm) + o, key0, Nk, fi < H);
+        bf[t] = th_frag(reinterpret_cast<const bf16*>(P) + o, key0, Nk, fi < H);
+        if (fi == TH_MAXH) bf[t] = th_ones(key0, Nk);
+      }
+#pragma unroll
+      for (int t = 0; t < TH_KSTEPS; ++t) tWw = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t], bf[t], tWw, 0, 0, 0);
     }
 #pragma unroll
     for (int hp = 0; hp < TH_MAXH; ++hp) dot[hp] = wave_sum_dpp(dot[hp]);
     {
       Keep4<T> pk[TH_MAXH], sk[TH_MAXH], ok[TH_MAXH];
+      bf16x4 dsk[MF ? TH_MAXH : 1];                 // MF: dS' of this lane's four keys, per head
 #pragma unroll
       for (int h = 0; h < TH_MAXH; ++h) {
         const int64_t o = ((b * H + (h < H ? h : 0)) * N + i) * ld;
@@ -252,11 +301,16 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const T* __restrict
           sv[hp] = sk[hp].get(c);
         }
         // through proj_l: dS[h] = sum_hp Wl[hp][h] dS'[hp];  dWl[hp][h] += dS'[hp] * S[h]
+        if constexpr (!MF) {
 #pragma unroll
-        for (int hp = 0; hp < TH_MAXH; ++hp) {
-          abl[hp] += ds[hp];
+          for (int hp = 0; hp < TH_MAXH; ++hp) {
+            abl[hp] += ds[hp];
 #pragma unroll
-          for (int h = 0; h < TH_MAXH; ++h) aWl[hp][h] = fmaf(ds[hp], sv[h], aWl[hp][h]);
+            for (int h = 0; h < TH_MAXH; ++h) aWl[hp][h] = fmaf(ds[hp], sv[h], aWl[hp][h]);
+          }
+        } else {
+#pragma unroll
+          for (int hp = 0; hp < TH_MAXH; ++hp) dsk[hp][c] = (bf16)ds[hp];
         }
 #pragma unroll
         for (int h = 0; h < TH_MAXH; ++h) {
@@ -269,6 +323,30 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const T* __restrict
 #pragma unroll
       for (int h = 0; h < TH_MAXH; ++h)
         if (h < H) th_store<T, VEC>(dS + ((b * H + h) * N + i) * ld, lane, Nk, ok[h]);
+      if constexpr (MF) {   // dS' -> the wave's tile [head][key] (VEC: this lane's keys are 4 lane .. 4 lane + 3)
+#pragma unroll
+        for (int hp = 0; hp < TH_MAXH; ++hp)
+          *reinterpret_cast<bf16x4*>(dstile + (w * TH_MAXH + hp) * TH_DSP + lane * 8) = dsk[hp];
+      }
+    }
+    if constexpr (MF) {     // dWl[hp][h] += sum_key dS'[hp][key] S[h][key]
+      asm volatile("" ::: "memory");                // the tile stores above are not to move below these reads
+      const int64_t o = ((b * H + (fi < H ? fi : 0)) * N + i) * ld;      // (same-wave LDS operations execute in order)
+      bf16x8 af[TH_KSTEPS], bf[TH_KSTEPS];
+#pragma unroll
+      for (int t = 0; t < TH_KSTEPS; ++t) {
+        const int key0 = 32 * t + 8 * fg;
+        af[t] = *reinterpret_cast<const bf16x8*>(dstile + (w * TH_MAXH + (fi & (TH_MAXH - 1))) * TH_DSP + key0 * 2);
+        if (fi >= TH_MAXH) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) af[t][e] = (bf16)0.f;
+        }
+        bf[t] = th_frag(reinterpret_cast<const bf16*>(S) + o, key0, Nk, fi < H);
+        if (fi == TH_MAXH) bf[t] = th_ones(key0, Nk);
+      }
+#pragma unroll
+      for (int t = 0; t < TH_KSTEPS; ++t) tWl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t], bf[t], tWl, 0, 0, 0);
+      asm volatile("" ::: "memory");                // ... nor the next row's stores above these reads
     }
   }
   // ---- 144 per-lane accumulators -> one partial row per wave.  A plain wave_sum per value
@@ -276,6 +354,23 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const T* __restrict
   // themselves); the transposing butterfly halves the value count at each of the first four
   // lane bits (72 + 36 + 18 + 9 shuffles), then two plain steps fold the last 9 values.
   constexpr int NV = 2 * TH_MAXH * TH_MAXH + 2 * TH_MAXH;     // 144, padded layout
+  __shared__ float wred[4][NV];
+  if constexpr (MF) {
+    // the accumulator tiles ARE the sums over the wave's keys: rows m = 4 fg + r (heads of the
+    // A operand), column fi (heads of B, column 8 = the ones row)
+    constexpr int HH = TH_MAXH * TH_MAXH;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = 4 * fg + r;
+      if (m < TH_MAXH && fi < TH_MAXH) {
+        wred[w][m * TH_MAXH + fi] = tWl[r];
+        wred[w][HH + TH_MAXH + m * TH_MAXH + fi] = tWw[r];
+      } else if (m < TH_MAXH && fi == TH_MAXH) {
+        wred[w][HH + m] = tWl[r];
+        wred[w][2 * HH + TH_MAXH + m] = tWw[r];
+      }
+    }
+  } else {
   float v[NV];
 #pragma unroll
   for (int a = 0; a < TH_MAXH; ++a) {
@@ -306,13 +401,13 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const T* __restrict
     v[k] += __shfl_xor(v[k], 16, 64);
     v[k] += __shfl_xor(v[k], 32, 64);
   }
-  // the four waves of the workgroup fold through LDS (fixed order) into ONE partial row per
-  // workgroup: the row fold that follows then walks 512 rows, not 2048
-  __shared__ float wred[4][NV];
   if (lane < 16) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) wred[w][base + k] = v[k];       // index in the padded layout
   }
+  }
+  // the four waves of the workgroup fold through LDS (fixed order) into ONE partial row per
+  // workgroup: the row fold that follows then walks 512 rows, not 2048
   __syncthreads();
   const int stride = 2 * H * H + 2 * H;
   float* prow = part + (int64_t)blockIdx.x * stride;
@@ -338,7 +433,8 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const T* __restrict
 
 inline int th_bwd_blocks(int64_t rows) {
   int64_t b = (rows + 3) / 4;
-  return (int)(b < 512 ? b : 512);      // one partial row per workgroup: keep the fold short
+  return (int)(b < 512 ? b : 512);      // one partial row per workgroup: keep the fold short (768 and 1024 workgroups with the
+                                        // register bound lowered to three / four waves per SIMD measured slower: 86 / 99 vs 71 us)
 }
 
 // ---- class attention: one wave per (b, h); q [B, H*hd] (already scaled by the caller via
@@ -509,6 +605,9 @@ extern "C" size_t vitmi_th_softmax_bwd_workspace(int64_t B, int64_t H, int64_t N
   return (size_t)th_bwd_blocks(B * N) * (size_t)(2 * H * H + 2 * H) * sizeof(float);
 }
 
+static int g_th_mfma = 1;   // diagnostic / test hook: 0 = parameter gradients on per-lane FMAs only
+extern "C" void vitmi_debug_th_mfma(int on) { g_th_mfma = on; }
+
 extern "C" int vitmi_th_softmax_bwd(const void* S, const void* P, const void* dPm, const float* Wl,
                                     const float* Ww, void* dS, float* dWl, float* dbl, float* dWw,
                                     float* dbw, int dtype, int64_t B, int64_t H, int64_t N, int64_t Nk,
@@ -523,9 +622,10 @@ extern "C" int vitmi_th_softmax_bwd(const void* S, const void* P, const void* dP
   float* part = reinterpret_cast<float*>(workspace);
   const size_t va = dtype == VITMI_BF16 ? 8 : 16;
   const bool vec = ld % 4 == 0 && ld >= (Nk + 3) / 4 * 4 && is_aligned(S, va) && is_aligned(P, va) && is_aligned(dPm, va) && is_aligned(dS, va);
-#define TH_BWD(T, V) hipLaunchKernelGGL((th_softmax_bwd_kernel<T, V>), dim3(nblk), dim3(256), 0, stream, (const T*)S, (const T*)P, (const T*)dPm, Wl, Ww, (T*)dS, part, rows, (int)H, (int)N, (int)Nk, (int)ld)
-  if (dtype == VITMI_BF16) { if (vec) TH_BWD(bf16, true); else TH_BWD(bf16, false); }
-  else if (dtype == VITMI_F32) { if (vec) TH_BWD(float, true); else TH_BWD(float, false); }
+#define TH_BWD(T, V, MFV) hipLaunchKernelGGL((th_softmax_bwd_kernel<T, V, MFV>), dim3(nblk), dim3(256), 0, stream, (const T*)S, (const T*)P, (const T*)dPm, Wl, Ww, (T*)dS, part, rows, (int)H, (int)N, (int)Nk, (int)ld)
+  const bool mf = g_th_mfma != 0 && vec && dtype == VITMI_BF16 && ld % 8 == 0 && is_aligned(S, 16) && is_aligned(P, 16) && is_aligned(dPm, 16);
+  if (dtype == VITMI_BF16) { if (mf) TH_BWD(bf16, true, true); else if (vec) TH_BWD(bf16, true, false); else TH_BWD(bf16, false, false); }
+  else if (dtype == VITMI_F32) { if (vec) TH_BWD(float, true, false); else TH_BWD(float, false, false); }
   else return vitmi_fail(VITMI_E_DTYPE, "th_softmax_bwd: bad dtype");
 #undef TH_BWD
   rc = vitmi_check_launch("th_softmax_bwd_kernel");
