@@ -347,7 +347,18 @@ def test_patchify(ops, B, C, H, p, cls, channels_last):
     assert torch.equal(outb.cpu(), want.reshape(out.shape).to(torch.bfloat16))
 
 
-@pytest.mark.parametrize("M,N", [(1, 8), (50, 10), (777, 768), (4000, 2304), (256, 197 * 64), (33, 7)])
+def test_colsum_narrow_strided_rows(ops):
+    """N <= 512 takes the rows-per-workgroup kernel; rows may sit at a larger stride."""
+    M, N, ld = 1234, 96, 288
+    x = bf16_round(gen((M, ld), 3))
+    xd = dev(x, torch.bfloat16)
+    out = torch.empty(N, device="cuda")
+    ops.colsum(xd[:, 96:192], out, M=M, N=N, ld=ld)
+    assert_close("colsum strided", out, x[:, 96:192].double().sum(0).float(), 1e-5)
+
+
+@pytest.mark.parametrize("M,N", [(1, 8), (50, 10), (777, 768), (4000, 2304), (256, 197 * 64), (33, 7),
+                                 (5000, 96), (50176, 96), (1234, 384), (300, 512), (3, 4)])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_colsum(ops, M, N, dt):
     x = gen((M, N), 1)

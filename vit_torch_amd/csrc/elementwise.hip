@@ -110,6 +110,33 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
   }
 }
 
+// The same for NARROW matrices (N <= 512, 4-element vectors): with one row per wave a
+// 96-column row is a 192-B load by 24 of 64 lanes and every wave walks hundreds of them one
+// latency at a time (Swin stage 1: 401 408 x 96 in 93 us = 0.8 TB/s).  Here the 256 threads
+// of a workgroup tile R = 256 / (N / 4) consecutive rows per step (thread t: row t / gpr,
+// column group t % gpr, so a step is one contiguous run of R rows when ld == N); a thread
+// always meets the same column group, the R row classes meet in LDS in a fixed order.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_rows_kernel(const T* __restrict__ x, int64_t M, int gpr,
+                                                                  int64_t ld, float* __restrict__ part) {
+  __shared__ f32x4 red[256];
+  const int R = 256 / gpr;
+  const int rr = threadIdx.x / gpr, cg = threadIdx.x - rr * gpr;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (rr < R) {
+    const T* p = x + cg * 4;
+#pragma unroll 4
+    for (int64_t r = (int64_t)blockIdx.x * R + rr; r < M; r += (int64_t)gridDim.x * R) acc += load4<T>(p + r * ld);
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < gpr) {
+    f32x4 t = red[threadIdx.x];
+    for (int k = 1; k < R; ++k) t += red[k * gpr + threadIdx.x];
+    *reinterpret_cast<f32x4*>(part + (int64_t)blockIdx.x * gpr * 4 + threadIdx.x * 4) = t;
+  }
+}
+
 // out[c] = sum_{r<S} part[r*ld + c], fixed summation order (deterministic).
 // Column sums of S partial rows.  The partial buffers are narrow (144 .. 2304 columns) and
 // tall (256 .. 2048 rows): with 64 columns per workgroup the grid was 3 .. 36 workgroups of
@@ -181,7 +208,7 @@ __global__ __launch_bounds__(1024) void reduce_rows_segs_kernel(const float* __r
 
 inline int colsum_splits(int64_t M) {
   int64_t s = (M + 3) / 4;
-  return (int)(s < 128 ? s : 128);
+  return (int)(s < 512 ? s : 512);
 }
 
 // ------------------------------------------------------------------ xent --
@@ -392,6 +419,14 @@ extern "C" int vitmi_colsum(const void* x, int dtype, int64_t M, int64_t N, int6
   const int S = colsum_splits(M);
   float* part = reinterpret_cast<float*>(workspace);
   const bool vec = (N % 4 == 0) && (ld % 4 == 0) && is_aligned(x, 4 * dtype_size(dtype));
+  if (vec && N <= 512 && (dtype == VITMI_BF16 || dtype == VITMI_F32)) {      // >= 2 rows per workgroup step
+    const int gpr = (int)(N / 4);
+    if (dtype == VITMI_BF16) hipLaunchKernelGGL((colsum_partial_rows_kernel<bf16>), dim3((unsigned)S), dim3(256), 0, stream, (const bf16*)x, M, gpr, ld, part);
+    else hipLaunchKernelGGL((colsum_partial_rows_kernel<float>), dim3((unsigned)S), dim3(256), 0, stream, (const float*)x, M, gpr, ld, part);
+    int rc = vitmi_check_launch("colsum_partial_rows_kernel");
+    if (rc) return rc;
+    return vitmi_reduce_rows(part, S, N, N, out, stream);
+  }
   const int cols_per_block = vec ? 256 : 64;
   dim3 grid((unsigned)((N + cols_per_block - 1) / cols_per_block), (unsigned)S);
   if (dtype == VITMI_BF16) {
