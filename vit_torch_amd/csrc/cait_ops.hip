@@ -555,6 +555,7 @@ __global__ __launch_bounds__(256) void colsum_mul_partial_kernel(const TX* __res
   const int64_t c0 = ((int64_t)blockIdx.x * 64 + lane) * 4;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   if (c0 < N)
+#pragma unroll 4
     for (int64_t r = (int64_t)blockIdx.y * 4 + w; r < M; r += (int64_t)gridDim.y * 4) {
       const f32x4 a = load4<TX>(x + r * ldx + c0), b = load4<TY>(y + r * ldy + c0);
 #pragma unroll
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(256) void colsum_mul_partial_kernel(const TX* __res
     }
 }
 
-inline int cm_splits(int64_t M) { int64_t s = (M + 3) / 4; return (int)(s < 128 ? s : 128); }
+inline int cm_splits(int64_t M) { int64_t s = (M + 3) / 4; return (int)(s < 512 ? s : 512); }
 
 }  // namespace
 
