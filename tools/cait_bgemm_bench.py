@@ -4,7 +4,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vit_torch_amd import ops  # noqa: E402
 
-B, Np, H, hd = 64, 196, 8, 48
+B, Np, H, hd = int(os.environ.get("BATCH", "64")), 196, 8, 48
 D, D3 = H * hd, 3 * H * hd
 NS = (Np + 7) // 8 * 8
 bt = torch.bfloat16

@@ -33,15 +33,14 @@ __device__ __forceinline__ bf16x8 zero8() {
   for (int e = 0; e < 8; ++e) z[e] = (bf16)0.f;
   return z;
 }
-// 8 consecutive k of row `row` (clamped by the caller), elements at k >= K read as zero
+// 8 consecutive k of row `row` (clamped by the caller), elements at k >= K read as zero.
+// The load is unconditional (a piece wholly beyond K re-reads the row's first piece and is
+// zeroed): a lane-dependent branch around it would give every fragment its own round trip.
 __device__ __forceinline__ bf16x8 row_frag(const bf16* X, int64_t ld, int row, int k, int K) {
-  if (k >= K) return zero8();
-  bf16x8 v = *reinterpret_cast<const bf16x8*>(X + (int64_t)row * ld + k);
-  if (k + 8 > K) {
+  bf16x8 v = *reinterpret_cast<const bf16x8*>(X + (int64_t)row * ld + (k < K ? k : 0));
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
-      if (k + e >= K) v[e] = (bf16)0.f;
-  }
+  for (int e = 0; e < 8; ++e)
+    if (k + e >= K) v[e] = (bf16)0.f;
   return v;
 }
 // operand fragment whose k runs along the ROWS of an LDS image [k][c] (row pitch RS bytes):
@@ -98,6 +97,34 @@ __device__ __forceinline__ void stage_rows(char* img, int RS, const bf16* X, int
     bf16x8 v = *reinterpret_cast<const bf16x8*>(X + (int64_t)min(r0 + r, R_total - 1) * ld + min(pc, last_pc));
     if (!ok) v = zero8();
     *reinterpret_cast<bf16x8*>(img + r * RS + pc * 2) = v;
+  }
+}
+
+// the same in two halves, so that a chunk's loads can fly while the previous chunk is
+// contracted: NP pieces of 16 B per thread (rows * cols_pad / 8 <= 256 * NP)
+template <int NP>
+__device__ __forceinline__ void load_rows(bf16x8 (&v)[NP], const bf16* X, int64_t ld, int r0, int rows, int R_total,
+                                          int cols, int cols_pad, int tid) {
+  const int cpr = cols_pad / 8, n = rows * cpr;
+  const int last_pc = (cols - 1) / 8 * 8;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int c = tid + i * 256, cc = min(c, n - 1);
+    const int r = cc / cpr, pc = (cc - r * cpr) * 8;
+    v[i] = *reinterpret_cast<const bf16x8*>(X + (int64_t)min(r0 + r, R_total - 1) * ld + min(pc, last_pc));   // unconditional
+    if (!(r0 + r < R_total && pc < cols)) v[i] = zero8();
+  }
+}
+template <int NP>
+__device__ __forceinline__ void store_rows(char* img, int RS, const bf16x8 (&v)[NP], int rows, int cols_pad, int tid) {
+  const int cpr = cols_pad / 8, n = rows * cpr;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int c = tid + i * 256;
+    if (c < n) {
+      const int r = c / cpr, pc = (c - r * cpr) * 8;
+      *reinterpret_cast<bf16x8*>(img + r * RS + pc * 2) = v[i];
+    }
   }
 }
 
@@ -158,6 +185,8 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(SmallArgs a) {
         f32x4 acc[SB_MAXN / 16];
 #pragma unroll
         for (int ct = 0; ct < SB_MAXN / 16; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // (all k-steps' fragments in one batch of loads was tried: 38 -> 144 VGPRs, three
+        // instead of eight waves per SIMD, 16.7 -> 28 us; occupancy hides this chain better)
         for (int ks = 0; ks < Kp / 32; ++ks) {
           const bf16x8 af = row_frag(A, a.lda, row, ks * 32 + 8 * g, K);
 #pragma unroll
@@ -183,10 +212,15 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(SmallArgs a) {
       for (int q = 0; q < RT_MAX; ++q)
 #pragma unroll
         for (int ct = 0; ct < SB_MAXN / 16; ++ct) acc[q][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // S streams through LDS one chunk at a time, the NEXT chunk's loads in registers meanwhile
+      constexpr int NP = SB_CHUNK * (256 / 8) / 256;           // M <= 256: <= 32 pieces per row, 64 rows, 256 threads
+      bf16x8 nxt[NP];
+      load_rows<NP>(nxt, A, a.lda, 0, min(SB_CHUNK, Kp), K, M, Mp, tid);
       for (int kc = 0; kc < Kp; kc += SB_CHUNK) {
         __syncthreads();                           // previous chunk consumed (and Ys staged)
         const int rows = min(SB_CHUNK, Kp - kc);
-        stage_rows(Ss, RSS, A, a.lda, kc, rows, K, M, Mp, tid, 256);
+        store_rows<NP>(Ss, RSS, nxt, rows, Mp, tid);
+        if (kc + SB_CHUNK < Kp) load_rows<NP>(nxt, A, a.lda, kc + SB_CHUNK, min(SB_CHUNK, Kp - kc - SB_CHUNK), K, M, Mp, tid);
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < RT_MAX; ++q) {
