@@ -73,6 +73,17 @@ def bdma(stage):
             out.append(f"buffer_load_dwordx4 {voff}, {rs}, s{so + i} offen lds")
     return out
 
+def bdma1(stage):
+    """STAGING=buf1: ONE M0 per operand and slab; piece i rides on the instruction offset i*1024, which
+    moves the LDS address AND the memory address, so its scalar offset register holds (row offset - 1024 i)"""
+    out = []
+    for op, (rs, voff, so) in enumerate((("s[52:55]", "%4", 60), ("s[56:59]", "%5", 64))):
+        out.append(f"s_add_u32 m0, %11, {stage * STAGE + op * 16384}")
+        out.append("s_nop 0")
+        for i in range(4):
+            out.append(f"buffer_load_dwordx4 {voff}, {rs}, s{so + i} offen offset:{i * 1024} lds")
+    return out
+
 def badvance():
     out = ["s_cmp_gt_i32 s44, 1", "s_cselect_b32 s48, 64, 0", "s_sub_i32 s44, s44, 1"]
     for r in range(60, 68): out.append(f"s_add_u32 s{r}, s{r}, s48")
@@ -159,14 +170,17 @@ def loop_body(wave):
 # ---- prologue
 e("s_mov_b64 s[40:41], %6"); e("s_mov_b64 s[42:43], %7"); e("s_mov_b32 s44, %10"); e("s_lshr_b32 s45, %10, 2")
 for i in range(256): e(f"v_accvgpr_write_b32 a{i}, 0")
-if STAGING == "buf":
+if STAGING in ("buf", "buf1"):
     e("s_mov_b64 s[52:53], %6"); e("s_mov_b32 s54, -1"); e("s_mov_b32 s55, 0x00020000")
     e("s_mov_b64 s[56:57], %7"); e("s_mov_b32 s58, -1"); e("s_mov_b32 s59, 0x00020000")
     e("s_mov_b32 s60, 0"); e("s_mov_b32 s64, 0")
     for i in range(1, 4):
         e(f"s_add_u32 s{60 + i}, s{59 + i}, %8"); e(f"s_add_u32 s{64 + i}, s{63 + i}, %9")
+    if STAGING == "buf1":
+        for i in range(1, 4):
+            e(f"s_sub_u32 s{60 + i}, s{60 + i}, {1024 * i}"); e(f"s_sub_u32 s{64 + i}, s{64 + i}, {1024 * i}")
     for st in range(3):
-        L.extend(bdma(st)); L.extend(badvance())
+        L.extend((bdma1 if STAGING == "buf1" else bdma)(st)); L.extend(badvance())
     e("s_waitcnt vmcnt(8)"); e("s_barrier")
 elif STAGING == "dma":
     for st in range(3):
@@ -197,6 +211,8 @@ for j in range(0 if STAGGER else 4):
         aux = gloads(j & 1) + advance() + reads((j + 1) & 1, (j + 1) & 3) + ["s_waitcnt vmcnt(8)"] + lwrites((j + 1) & 1, (j + 2) & 3)
     elif STAGING == "buf":
         aux = bdma((j + 3) & 3) + badvance() + reads((j + 1) & 1, (j + 1) & 3)
+    elif STAGING == "buf1":
+        aux = bdma1((j + 3) & 3) + badvance() + reads((j + 1) & 1, (j + 1) & 3)
     elif ORDER == "dma_first":
         aux = dma((j + 3) & 3) + advance() + reads((j + 1) & 1, (j + 1) & 3)
     else:
