@@ -221,7 +221,13 @@ for j in range(0 if STAGGER else 4):
         aux = [os.environ["FILL"]] * int(os.environ.get("NFILL", "32"))
     if NO_READS: aux = [x for x in aux if not x.startswith("ds_read")]
     if NO_DMA: aux = [x for x in aux if x.startswith("ds_read")]
-    L.extend(interleave(mfmas(j & 1), aux))
+    if os.environ.get("BURST") == "1":               # diagnostic: all staging in one burst after the first MFMA
+        mf = mfmas(j & 1)
+        st = [x for x in aux if not x.startswith("ds_read")]
+        rd = [x for x in aux if x.startswith("ds_read")]
+        L.extend([mf[0]] + st + interleave(mf[1:], rd))
+    else:
+        L.extend(interleave(mfmas(j & 1), aux))
     if not NO_VM and STAGING != "vgpr": e("s_waitcnt vmcnt(8)")
     e("s_waitcnt lgkmcnt(0)")
     if not NO_BAR: e("s_barrier")
