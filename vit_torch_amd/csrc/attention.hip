@@ -666,7 +666,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
 template <int HD> struct FusedBwdCfg {
   static constexpr int QS = AttnCfg<HD>::KS;     // staged Q / dO / K row (bytes)
   static constexpr int DQS = HD * 4 + 16;        // fp32 dQ row (bytes)
-  static constexpr int ROW_BYTES = 2 * QS + DQS + 8 + 64;   // + lse, delta, dS tile share
+  static constexpr int TPITCH = 80;              // dS tile row pitch (bytes): 64 B of keys + pad against bank conflicts
+  static constexpr int ROW_BYTES = 2 * QS + DQS + 8 + TPITCH;   // + lse, delta, dS tile share
 };
 
 template <int HD, bool DBIAS>
@@ -696,7 +697,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16* __restr
   char* dQl = dOl + NP * QS;                       // first the K staging, then fp32 dQ
   float* lse_s = reinterpret_cast<float*>(dQl + NP * DQS);
   float* del_s = lse_s + NP;
-  char* Tl = reinterpret_cast<char*>(del_s + NP) + w * 2048;
+  char* Tl = reinterpret_cast<char*>(del_s + NP) + w * 32 * F::TPITCH;
   const int bh = blockIdx.x, b = bh / H, h = bh % H;
   const int64_t ts = (int64_t)3 * H * HD;
   const int64_t os = (int64_t)H * HD;
@@ -840,13 +841,13 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16* __restr
       bf16x4 o4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o4[e] = (bf16)dp[4 * g + e];
-      *reinterpret_cast<bf16x4*>(Tl + lr * 64 + (8 * g + 4 * h5) * 2) = o4;
+      *reinterpret_cast<bf16x4*>(Tl + lr * F::TPITCH + (8 * g + 4 * h5) * 2) = o4;
     }
     // dS^T back (same wave: DS operations execute in order); the dV / dK products cover
     // the round trip
     bf16x8 bT[2];
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) bT[s2] = load_tr_frag(Tl, 64, 16 * s2, 0, lane);
+    for (int s2 = 0; s2 < 2; ++s2) bT[s2] = load_tr_frag(Tl, F::TPITCH, 16 * s2, 0, lane);
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       const bf16x8 pf = pack8(s, 8 * s2);
