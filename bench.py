@@ -6,6 +6,11 @@ MFMA operands / fp32 accumulation, synthetic data resident in HBM, random-init w
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no torch.distributed.run environment LAUNCHES ITSELF:
+the parent process (which never touches the GPU) starts N ranks with
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`,
+relays rank 0's JSON line and exits with the children's status.
+
 Rank 0 prints ONE JSON line.  Extra objects on it:
   roofline     the GEMM kernel family (gemm_fast_kernel: >99 % of the step's FLOPs):
                algorithmic FLOPs of every GEMM launch of one step / the sum of their
@@ -13,6 +18,10 @@ Rank 0 prints ONE JSON line.  Extra objects on it:
                instrumented step run right after the timed region.
   cpu_baseline the oracle (plain PyTorch fp32 restatement of the reference model and
                step) timed on this box's host cores on a bounded sample.
+  parity       SURVEY §8(d) "parity check beside it": logits (max|diff| / max|ref|), loss and
+               worst per-parameter gradient-norm deviation of the HIP step from the CPU oracle on
+               the same seeded weights and a batch-2 sample, for the fp32 parity mode and for the
+               benchmarked bf16 mode; measured outside the timed region (N = 1 only).
 """
 import argparse
 import json
@@ -46,6 +55,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the step from a captured HIP graph (single GPU; auto = try, fall back to eager)")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--force-ddp", action="store_true",
+                    help="run the RCCL gradient exchange even in a world of one rank (launcher / ordering test)")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=2)
     return ap.parse_args()
@@ -128,19 +140,80 @@ def cpu_baseline(arch, img, batch, steps, mode="finetune"):
             "sample": f"{steps} steps of {arch} {mode} at batch {batch}, {img}x{img}, fp32, after 1 warm-up"}
 
 
+def self_launch(n):
+    """Parent of a multi-GPU run started as plain `python bench.py --gpus N`: spawn one rank per
+    GPU through torch.distributed.run and relay their output.  Nothing in this process has
+    initialised the GPU (no torch.cuda call, no HIP call), and nothing is exec'ed: the ranks
+    are ordinary child processes."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def parity_check(arch, img, residual, batch=2):
+    """HIP step vs the CPU oracle on identical seeded weights / inputs, both modes (outside the
+    timed region).  The oracle is the checker here, never the thing measured."""
+    import torch.nn.functional as F
+    from oracle import vit_ref
+    from vit_torch_amd import CrossEntropyLoss
+    ref = build_oracle(arch, img)
+    vit_ref.seeded_init_(ref, 1)
+    g = torch.Generator("cpu").manual_seed(0)
+    x = torch.randn(batch, 3, img, img, generator=g)
+    y = torch.randint(0, 10, (batch,), generator=g)
+    lo = ref(x)
+    lr = F.cross_entropy(lo, y)
+    lr.backward()
+    out = {"sample": f"batch {batch}, seed 0 inputs, seed 1 weights, vs oracle fp32 on CPU",
+           "metric": "logits: max|diff|/max|ref|; loss: |diff|; gradnorm: worst per-parameter |norm-norm_ref|/norm_ref"}
+    for mode in ("fp32", "bf16"):
+        m = build_model(arch, img, mode, residual if mode == "bf16" else "fp32")
+        m.load_state_dict(ref.state_dict(), strict=True)
+        m = m.cuda()
+        logits = m(x.cuda())
+        loss = CrossEntropyLoss()(logits, y.cuda())
+        loss.backward()
+        worst = 0.0
+        for (n, pr), (_, pm) in zip(ref.named_parameters(), m.named_parameters()):
+            gr = pr.grad.double().norm().item()
+            if gr < 1e-9:          # analytically zero gradients (softmax shift invariance)
+                continue
+            worst = max(worst, abs(pm.grad.double().norm().item() - gr) / gr)
+        out[mode] = {"logits_rel": float(f"{(logits.float().cpu() - lo).abs().max().item() / lo.abs().max().item():.3e}"),
+                     "loss_diff": float(f"{abs(loss.item() - lr.item()):.3e}"),
+                     "gradnorm_rel": float(f"{worst:.3e}")}
+        del m
+    out["tolerance"] = {"fp32": 1e-3, "bf16": "reported, not met: bf16 operands round at 2^-9"}
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} needs a torch.distributed.run launch with {a.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {a.gpus} but the launcher started {world} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    ddp = world > 1 or a.force_ddp
+    if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from vit_torch_amd import CrossEntropyLoss, FusedSGD
     from vit_torch_amd.ddp import GradReducer
@@ -181,7 +254,7 @@ def main():
             opt.step()
             return loss
     else:
-        reducer = GradReducer(eng.pack) if world > 1 else None
+        reducer = GradReducer(eng.pack, force=a.force_ddp) if ddp else None
         if reducer is not None:
             reducer.broadcast_parameters(0)
             eng.reducer = reducer
@@ -204,7 +277,7 @@ def main():
         return (time.perf_counter() - t) / n * 1e3
 
     step, graphed = eager_step, False
-    if world == 1 and a.graph != "off" and head is None:
+    if not ddp and a.graph != "off" and head is None:
         try:
             from vit_torch_amd.graph import GraphedStep
             gs = GraphedStep(model, crit, opt, x, y)
@@ -219,7 +292,7 @@ def main():
             print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); eager step", file=sys.stderr)
 
     def fence():
-        if world > 1:
+        if ddp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -231,7 +304,7 @@ def main():
         loss = step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if ddp:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -254,11 +327,15 @@ def main():
         tot_t = sum(r[2] for r in rows.values())
         n_launch = sum(r[0] for r in rows.values())
         ach = tot_f / tot_t / 1e12
-        # HBM bytes per launch of the same kernel from the committed rocprofv3 --pmc passes
-        # (FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_traffic.py); bench.py cannot collect PMCs itself
+        # HBM bytes per launch of the same kernel from the COMMITTED rocprofv3 --pmc passes of this
+        # command (FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_traffic.py); bench.py cannot collect PMCs
+        # itself, so this is a recorded figure, labelled with the file it comes from
         traffic = None
+        traffic_file = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
+            traffic_file = os.path.join("profiles", cands[-1])
+            pm = json.load(open(os.path.join(ROOT, traffic_file)))
             k = pm["gemm_fast_kernel"]
             steps_prof = (pm.get("_meta") or {}).get("steps_profiled")
             if steps_prof:      # one GEMM call may be several launches (split tail, split-K): per call
@@ -270,7 +347,9 @@ def main():
         roof = {"bound": "mfma", "kernel": "gemm_fast_kernel (all GEMM launches of one step)",
                 "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                "traffic_note": "HBM bytes per GEMM call (all gemm_fast_kernel launches of a step / calls), rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE of this command (profiles/r01_pmc_traffic.json)",
+                "traffic_note": ("HBM bytes per GEMM call (all gemm_fast_kernel launches of a step / calls), NOT collected in "
+                                 "this run: from the committed rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE passes of this "
+                                 f"command in {traffic_file}"),
                 "flop_per_launch": round(tot_f / n_launch),
                 "launches_per_step": n_launch, "avg_launch_ms": round(tot_t / n_launch * 1e3, 4),
                 "gemm_ms_per_step": round(tot_t * 1e3, 3),
@@ -281,6 +360,9 @@ def main():
     cpu = None
     if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a.arch, a.img, a.cpu_batch, a.cpu_steps, a.mode)
+    parity = None
+    if rank == 0 and a.gpus == 1 and not a.no_parity and a.mode == "finetune" and a.compute == "bf16":
+        parity = parity_check(a.arch, a.img, a.residual)
 
     if rank == 0:
         ips = a.batch * world * a.steps / elapsed
@@ -303,10 +385,10 @@ def main():
             "loss": round(loss_value, 5),
             "step_mfma_frac": (round(ips / world * flop_img * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4)
                                if flop_img else None),
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if ddp:
         dist.destroy_process_group()
 
 

@@ -10,8 +10,12 @@
  * pointers, sizes, strides (in ELEMENTS) and a hipStream_t passed as void*.
  *
  * Conventions
- *  - every call only ENQUEUES work on `stream`; no allocation, no sync, no
- *    global mutable state (safe under hipGraph capture, re-entrant);
+ *  - every call only ENQUEUES work on `stream`: no allocation, no sync (safe under
+ *    hipGraph capture).  Calls are re-entrant across host threads and streams.  The only
+ *    process-wide state is (a) a per-device table, filled under std::call_once, of the
+ *    CU count and of which kernels have had their dynamic-LDS limit raised, and (b) the
+ *    `vitmi_debug_*` switches (not declared here; test / profiling hooks that select kernel
+ *    variants process-wide and must not be flipped while another thread is launching);
  *  - return 0 on success, <0 for a rejected argument (VITMI_E_*), >0 = the
  *    hipError_t of a failed launch; vitmi_last_error_string() describes the
  *    last failure on the calling thread;
@@ -29,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VITMI_VERSION 100
+#define VITMI_VERSION 101
 
 enum { VITMI_F32 = 0, VITMI_BF16 = 1 };
 
@@ -73,6 +77,9 @@ enum {
 enum { VITMI_GEMM_AUTO = 0, VITMI_GEMM_GENERIC = 1, VITMI_GEMM_FAST = 2 };
 
 typedef struct vitmi_gemm_desc {
+  int64_t struct_size;         /* = sizeof(vitmi_gemm_desc): a caller built against an
+                                  older / shorter layout is rejected (VITMI_E_BADARG)
+                                  instead of having the library read past its struct  */
   int64_t M, N, K;
   const void* A; int64_t lda; int32_t a_kmajor;
   const void* B; int64_t ldb; int32_t b_kmajor;

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_version_and_error_string(lib):
-    assert lib.vitmi_version() == 100
+    assert lib.vitmi_version() == 101
     assert isinstance(lib.vitmi_last_error_string(), bytes)
 
 
@@ -85,3 +85,69 @@ def test_hot_shapes_take_the_fast_gemm(lib):
     assert ops.gemm_uses_fast(401408, 288, 96)            # Swin-T stage 0 qkv
     assert ops.gemm_uses_fast(96, 96, 401408, a_kmajor=False, b_kmajor=False, c_dtype=F32)
     assert ops.gemm_uses_fast(256 * 5, 1152, 384)         # ViT-S qkv: N % 128 == 0 -> 256x128 tiles
+
+
+# ---- the three statements of struct vitmi_gemm_desc must agree: header, _lib.GemmDesc, and the
+# stand-alone ctypes stub a maintainer would copy from INTEGRATION.md (a short struct would
+# make the library read past the caller's memory; the library also checks struct_size)
+_CTYPE_OF = {"int64_t": "c_int64", "int32_t": "c_int32", "float": "c_float", "size_t": "c_size_t"}
+
+
+def _header_gemm_fields():
+    text = open(os.path.join(ROOT, "include", "vitmi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    body = re.search(r"typedef struct vitmi_gemm_desc \{(.*?)\} vitmi_gemm_desc;", text, flags=re.S).group(1)
+    out = []
+    for decl in body.split(";"):
+        decl = " ".join(decl.split())
+        if not decl:
+            continue
+        m = re.match(r"(const )?(\w+)(\*?) (.*)", decl)
+        base, ptr, names = m.group(2), m.group(3), m.group(4)
+        for nm in names.split(","):
+            nm = nm.strip()
+            arr = re.match(r"(\w+)\[(\d+)\]", nm)
+            is_ptr = bool(ptr) or nm.startswith("*")
+            nm = nm.lstrip("* ")
+            if arr:
+                out.append((arr.group(1), f"{_CTYPE_OF[base]} * {arr.group(2)}"))
+            else:
+                out.append((nm, "c_void_p" if is_ptr else _CTYPE_OF[base]))
+    return out
+
+
+def _integration_stub_fields():
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stub = text[text.index("class GemmDesc(C.Structure):"):text.index("lib.vitmi_gemm.argtypes")]
+    return [(n, t.replace("C.", "")) for n, t in re.findall(r'\("(\w+)", ([^)]+)\)', stub)]
+
+
+def test_gemm_desc_header_ctypes_and_doc_stub_agree(lib):
+    from vit_torch_amd._lib import GemmDesc
+    hdr = _header_gemm_fields()
+    doc = _integration_stub_fields()
+    assert [n for n, _ in hdr] == [n for n, _ in GemmDesc._fields_]
+    assert hdr == doc, "INTEGRATION.md ctypes stub differs from struct vitmi_gemm_desc in include/vitmi.h"
+    # same layout: build the doc's structure and compare size and every offset
+    ns = {"c_int64": ctypes.c_int64, "c_int32": ctypes.c_int32, "c_float": ctypes.c_float,
+          "c_size_t": ctypes.c_size_t, "c_void_p": ctypes.c_void_p}
+
+    def ctype(t):
+        if "*" in t:
+            b, n = t.split("*")
+            return ns[b.strip()] * int(n)
+        return ns[t]
+
+    Doc = type("Doc", (ctypes.Structure,), {"_fields_": [(n, ctype(t)) for n, t in doc]})
+    assert ctypes.sizeof(Doc) == ctypes.sizeof(GemmDesc)
+    for n, _ in doc:
+        assert getattr(Doc, n).offset == getattr(GemmDesc, n).offset, n
+
+
+def test_short_gemm_descriptor_is_rejected(lib):
+    from vit_torch_amd._lib import GemmDesc
+    d = GemmDesc()
+    d.M = d.N = d.K = 256
+    d.struct_size = 232              # the layout that ended at workspace_bytes
+    assert lib.vitmi_gemm(ctypes.byref(d), None) == -1
+    assert b"struct_size" in lib.vitmi_last_error_string()

@@ -248,8 +248,8 @@ def test_cait_tiny_fp32_matches_oracle():
 def test_cait_tiny_bf16_close_to_oracle(residual):
     ref, m = make_pair(TINY, "bf16", residual)
     lo, lr, out, loss = step(ref, m, 6, 32)
-    e = assert_close("logits", out, lo, 3e-2)
-    assert abs(loss.item() - lr.item()) < 2e-2
+    e = assert_close("logits", out, lo, 1e-2)      # measured 2.1-3.4e-3 (round 2)
+    assert abs(loss.item() - lr.item()) < 5e-3
     worst = 0.0
     for (n, pr), (_, pm) in zip(ref.named_parameters(), m.named_parameters()):
         if zero_grad_param(n):
@@ -257,7 +257,7 @@ def test_cait_tiny_bf16_close_to_oracle(residual):
         gn_ref, gn = pr.grad.norm().item(), pm.grad.float().norm().item()
         rel = abs(gn - gn_ref) / max(gn_ref, 1e-12)
         worst = max(worst, rel)
-        assert rel < 8e-2, f"grad-norm[{n}]: {gn:.4g} vs {gn_ref:.4g}"
+        assert rel < 1.2e-2, f"grad-norm[{n}]: {gn:.4g} vs {gn_ref:.4g}"      # measured 3.0-4.3e-3
     print(f"\ncait tiny bf16 (residual {residual}): logits rel err {e:.2e}, worst grad-norm rel err {worst:.2e}")
 
 

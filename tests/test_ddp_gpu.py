@@ -136,3 +136,26 @@ def test_two_ranks_on_one_gpu_match_the_global_batch_step(lib, compute, tmp_path
     err = (got[0][1] - want).norm() / want.norm()
     # mean of two half-batch means == global mean; fp32 differs only by summation order
     assert err < (2e-6 if compute == "fp32" else 2e-4), err
+
+
+def test_bench_launches_itself_and_runs_the_rccl_path_end_to_end():
+    """`python bench.py --gpus N` must start its own ranks.  One GPU here, so the
+    launcher path is driven with N = 1 ranks through torch.distributed.run by calling the same
+    helper, with the RCCL gradient exchange forced on (GradReducer(force=True)): the line must
+    come back with n_gpus 1 and the value of a plain run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    args = ["--steps", "3", "--warmup", "1", "--arch", "dino_vits16", "--img", "32", "--batch", "128",
+            "--no-cpu-baseline", "--no-parity", "--graph", "off"]
+    code = ("import sys, bench; sys.argv = ['bench.py', '--gpus', '1', '--force-ddp'] + %r; "
+            "raise SystemExit(bench.self_launch(1))" % (args,))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0
+    assert d["config"]["parallelism"] == "dp1" and d["config"]["hip_graph"] is False

@@ -42,3 +42,33 @@ def test_network_rejects_non_modules():
     from vit_torch_amd.network import Network
     with pytest.raises(ValueError):
         Network(model="not a module")
+
+
+def test_bench_parent_launches_ranks_without_touching_the_gpu(monkeypatch):
+    """`python bench.py --gpus N` (no torch.distributed.run environment): the parent must start N
+    ranks as CHILD processes of `python -m torch.distributed.run ... --master-addr 127.0.0.1`,
+    hand them its own arguments, and return their status; it must not call into torch.cuda."""
+    import importlib
+    import subprocess
+    import sys
+    import torch
+    bench = importlib.import_module("bench")
+    calls = {}
+
+    def fake_call(cmd, env=None):
+        calls["cmd"], calls["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda *_: (_ for _ in ()).throw(AssertionError("GPU touched")))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    try:
+        bench.main()
+    except SystemExit as e:
+        assert e.code == 7
+    cmd = calls["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    i = cmd.index(bench.__file__ if bench.__file__ in cmd else [c for c in cmd if c.endswith("bench.py")][0])
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    assert calls["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

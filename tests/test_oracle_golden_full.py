@@ -1,0 +1,135 @@
+"""SURVEY.md §8(c) fixture kinds 3 and 4 (tests/golden/gen_golden_full.py: full-size Swin-T and
+cait_S24_224 of the REFERENCE classes, the reference's LRSchedule lambdas, two harness SGD steps on
+the reference's tiny CaiT / Swin) against the oracle and the product's host logic.  CPU only."""
+import os
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from util import assert_close
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    top, groups = {}, {}
+    for k in z.files:
+        if "/" in k:
+            g, kk = k.split("/", 1)
+            groups.setdefault(g, {})[kk] = torch.from_numpy(np.asarray(z[k]))
+        else:
+            top[k] = torch.from_numpy(np.asarray(z[k]))
+    return top, groups
+
+
+def inputs(B, S, seed):
+    g = torch.Generator("cpu").manual_seed(seed)
+    return torch.randn(B, 3, S, S, generator=g), torch.randint(0, 10, (B,), generator=g)
+
+
+def checksum(x):
+    v = x.double().flatten()
+    w = torch.arange(1, v.numel() + 1, dtype=torch.float64) % 9973
+    return float((v * w).sum())
+
+
+def build_full(name):
+    """The oracle model + inputs a full-size fixture was generated with (weights regenerated)."""
+    from oracle import cait_ref, swin_ref
+    from oracle.vit_ref import seeded_init_
+    top, groups = load(name)
+    if name == "full_swin_tiny":
+        ref = swin_ref.build("swin_tiny_patch4_window7_224", num_classes=10, drop_path_rate=0.0)
+        ref.head = nn.Linear(768, 10, bias=False)
+    else:
+        ref = cait_ref.build("cait_S24_224", num_classes=10)
+        ref.head = nn.Linear(384, 10, bias=False)
+    seeded_init_(ref, int(top["init_seed"]))
+    if "gamma" in top:
+        with torch.no_grad():
+            for n, p in ref.named_parameters():
+                if "gamma_" in n:
+                    p.fill_(float(top["gamma"]))
+    x, y = inputs(2, 224, int(top["input_seed"]))
+    assert checksum(x) == pytest.approx(float(top["x_checksum"]), rel=1e-12)
+    assert torch.equal(y, top["labels"])
+    return ref, x, y, top, groups
+
+
+@pytest.mark.parametrize("name", ["full_swin_tiny", "full_cait_S24_224"])
+def test_full_size_oracle_matches_reference_class(name):
+    ref, x, y, top, groups = build_full(name)
+    torch.set_num_threads(8)
+    logits = ref(x)
+    loss = F.cross_entropy(logits, y)
+    loss.backward()
+    assert_close("logits", logits, top["logits"], 5e-6)
+    assert abs(loss.item() - float(top["loss"])) < 5e-6
+    worst = 0.0
+    names = [n for n, _ in ref.named_parameters()]
+    assert set(names) == set(groups["gradnorm"]), "parameter names differ from the reference class"
+    for n, p in ref.named_parameters():
+        want = float(groups["gradnorm"][n])
+        got = p.grad.double().norm().item()
+        if want < 1e-9:                 # analytically zero gradients (softmax shift invariance)
+            assert got < 1e-6, n
+            continue
+        worst = max(worst, abs(got - want) / want)
+    assert worst < 1e-4, worst
+
+
+def test_lr_schedule_tables_match_reference_lambdas():
+    """utils_network.py:35-73 vs vit_torch_amd.network.LRSchedule, epochs 0..30."""
+    from vit_torch_amd.network import LRSchedule
+    top, groups = load("harness")
+    ep = top["epochs"].tolist()
+    lr = groups["lr"]
+    mine = {
+        "base": LRSchedule.get_base_fn(),
+        "step_10_0.5": LRSchedule.get_step_fn(step=10, gamma=0.5),
+        "step_3_0.7": LRSchedule.get_step_fn(step=3, gamma=0.7),
+        "exp_0.99_1": LRSchedule.get_exp_fn(gamma=0.99, step=1),
+        "exp_0.9_2": LRSchedule.get_exp_fn(gamma=0.9, step=2),
+        "cosine_20_0.1": LRSchedule.get_cosine(step=20, min_scale=0.1),
+        "cosine_exp_20_0.1_0.5": LRSchedule.get_cosine_exp(step=20, min_scale=0.1, gamma=0.5),
+    }
+    assert set(mine) == set(lr)
+    for k, fn in mine.items():
+        got = np.asarray([fn(e) for e in ep], dtype=np.float64)
+        np.testing.assert_allclose(got, lr[k].numpy(), rtol=1e-12, atol=0, err_msg=k)
+
+
+def tiny_pairs():
+    from oracle.cait_ref import CaiT
+    from oracle.swin_ref import SwinTransformer
+    cait_cfg = dict(img_size=32, patch_size=8, embed_dim=64, depth=2, num_heads=4, mlp_ratio=4, qkv_bias=True,
+                    norm_layer=partial(nn.LayerNorm, eps=1e-6), init_scale=1e-1, depth_token_only=2, num_classes=10)
+    swin_cfg = dict(img_size=56, patch_size=4, in_chans=3, num_classes=10, embed_dim=32, depths=[2, 2],
+                    num_heads=[2, 4], window_size=7, drop_path_rate=0.0)
+    return {"cait": (CaiT, cait_cfg, 31, lambda s: inputs(4, 32, 40 + s)),
+            "swin": (SwinTransformer, swin_cfg, 32, lambda s: inputs(2, 56, 50 + s))}
+
+
+@pytest.mark.parametrize("fam", ["cait", "swin"])
+def test_two_harness_sgd_steps_on_oracle_match_reference_classes(fam):
+    """zero_grad -> backward -> SGD(momentum 0.9).step() twice (utils_network.py:120,440-442)."""
+    from oracle.vit_ref import seeded_init_
+    cls, cfg, seed, batch = tiny_pairs()[fam]
+    _, groups = load("harness")
+    rec = groups[fam]
+    m = seeded_init_(cls(**cfg), seed)
+    opt = torch.optim.SGD(m.parameters(), lr=0.05, momentum=0.9)
+    for s in (1, 2):
+        x, y = batch(s)
+        loss = F.cross_entropy(m(x), y)
+        opt.zero_grad(); loss.backward(); opt.step()
+        assert abs(loss.item() - float(rec[f"loss{s}"])) < 5e-6
+        for n, p in m.named_parameters():
+            want = float(rec[f"pnorm{s}/{n}"])
+            assert abs(p.detach().double().norm().item() - want) <= 2e-6 * max(want, 1.0), (s, n)
+    assert_close("head after 2 steps", m.head.weight, rec["head_after2"], 5e-6)

@@ -157,14 +157,14 @@ def test_swin_tiny_fp32_matches_oracle():
 def test_swin_tiny_bf16_close_to_oracle(residual):
     ref, m = make_pair(TINY, "bf16", residual)
     lo, lr, out, loss = step(ref, m, 4, 56)
-    e = assert_close("logits", out, lo, 3e-2)
-    assert abs(loss.item() - lr.item()) < 2e-2
+    e = assert_close("logits", out, lo, 1e-2)      # measured 2.1-3.4e-3 (round 2)
+    assert abs(loss.item() - lr.item()) < 5e-3
     worst = 0.0
     for (n, pr), (_, pm) in zip(ref.named_parameters(), m.named_parameters()):
         gn_ref, gn = pr.grad.norm().item(), pm.grad.float().norm().item()
         rel = abs(gn - gn_ref) / max(gn_ref, 1e-12)
         worst = max(worst, rel)
-        assert rel < 8e-2, f"grad-norm[{n}]: {gn:.4g} vs {gn_ref:.4g}"
+        assert rel < 1.2e-2, f"grad-norm[{n}]: {gn:.4g} vs {gn_ref:.4g}"      # measured 3.0-4.3e-3
     print(f"\nswin tiny bf16 (residual {residual}): logits rel err {e:.2e}, worst grad-norm rel err {worst:.2e}")
 
 
@@ -211,14 +211,14 @@ def test_swin_tiny_drop_path_matches_oracle_with_pinned_masks(compute):
         for (n, pr), (_, pm) in zip(ref.named_parameters(), m.named_parameters()):
             assert_close(f"grad[{n}]", pm.grad, pr.grad, 3e-4)
     else:
-        e = assert_close("logits", out, lo, 3e-2)
+        e = assert_close("logits", out, lo, 1e-2)
         for (n, pr), (_, pm) in zip(ref.named_parameters(), m.named_parameters()):
             gn_ref, gn = pr.grad.norm().item(), pm.grad.float().norm().item()
-            assert abs(gn - gn_ref) / max(gn_ref, 1e-12) < 8e-2, n
+            assert abs(gn - gn_ref) / max(gn_ref, 1e-12) < 1.2e-2, n
     # eval mode: DropPath is the identity (nn.Module semantics)
     m.eval()
     with torch.no_grad():
-        assert_close("eval logits", m(x.cuda()), ref(x), 1e-4 if compute == "fp32" else 3e-2)
+        assert_close("eval logits", m(x.cuda()), ref(x), 1e-4 if compute == "fp32" else 1e-2)
     print(f"\nswin tiny drop-path {compute}: logits rel err {e:.2e}, {dropped} dropped branches")
 
 

@@ -3,9 +3,11 @@ CPU oracle (oracle/vit_ref.py) on identical seeded weights and inputs.
 
 Tolerances (max|diff| / max|ref|):
   fp32 mode (parity mode): logits 1e-3 is the north-star bar; we assert 1e-4.
-  bf16 mode (perf mode: bf16 GEMM/attention operands, fp32 residual stream,
-  fp32 accumulation): logits 3e-2, loss 2e-2 abs, per-parameter grad-norm 8e-2.
-  These are measured, not assumed: the test prints the achieved numbers.
+  bf16 mode (perf mode: bf16 GEMM/attention operands, fp32 accumulation): bounds ~2x the
+  round-2 measurements on the MI355X (small model 4.2e-3 / 1.5e-4 / 1.8e-3 with the fp32
+  residual stream, 4.9e-3 / 4.2e-4 / 3.3e-3 with the bf16 one; ViT-B/16 @224 5.1e-3 / 4.0e-4 /
+  1.8e-3 and 8.8e-3 / 4.4e-3 / 2.6e-3): logits 1.2e-2 (fp32 residual) / 2e-2 (bf16 residual),
+  loss 2e-3 / 1e-2, per-parameter grad-norm 8e-3.  The tests print the achieved numbers.
 """
 import pytest
 import torch
@@ -14,6 +16,9 @@ import torch.nn.functional as F
 from util import assert_close, rel_err
 
 pytestmark = pytest.mark.gpu
+
+# (logits rel-to-max, |loss diff|, per-parameter grad-norm rel) by residual-stream dtype
+BF16_TOL = {"fp32": (1.2e-2, 2e-3, 8e-3), "bf16": (2e-2, 1e-2, 8e-3)}
 
 
 def make_pair(cfg, classifier, compute, residual="fp32", seed=1):
@@ -72,7 +77,7 @@ def test_fp32_mode_matches_oracle(cfg, classifier):
             continue
         assert pm.grad is not None, f"no grad for {n}"
         worst = max(worst, assert_close(f"grad[{n}]", pm.grad, pr.grad, 2e-4))
-    assert crit.last_correct.item() == (out_ref[:, :K].argmax(-1) == y).sum().item() or True
+    assert crit.last_correct.item() == (out_ref[:, :K].argmax(-1) == y).sum().item()
     print(f"\nfp32 mode: logits rel err {e:.2e}, loss diff {abs(loss.item()-loss_ref.item()):.2e}, worst grad rel err {worst:.2e}")
 
 
@@ -82,14 +87,14 @@ def test_bf16_mode_close_to_oracle(residual):
     ref, m = make_pair(cfg, classifier, "bf16", residual)
     x, y = data(8, 3, cfg["img_size"], K)
     out_ref, loss_ref, out, loss, _ = run_step(ref, m, x, y, K)
-    e = assert_close("logits", out, out_ref, 3e-2)
-    assert abs(loss.item() - loss_ref.item()) < 2e-2
+    e = assert_close("logits", out, out_ref, BF16_TOL[residual][0])
+    assert abs(loss.item() - loss_ref.item()) < BF16_TOL[residual][1]
     worst = 0.0
     for (n, pr), (_, pm) in zip(ref.named_parameters(), m.named_parameters()):
         gn_ref, gn = pr.grad.norm().item(), pm.grad.float().norm().item()
         rel = abs(gn - gn_ref) / max(gn_ref, 1e-12)
         worst = max(worst, rel)
-        assert rel < 8e-2, f"grad-norm[{n}]: {gn:.4g} vs {gn_ref:.4g}"
+        assert rel < BF16_TOL[residual][2], f"grad-norm[{n}]: {gn:.4g} vs {gn_ref:.4g}"
     print(f"\nbf16 mode (residual {residual}): logits rel err {e:.2e}, loss diff "
           f"{abs(loss.item()-loss_ref.item()):.2e}, worst grad-norm rel err {worst:.2e}")
 
@@ -172,7 +177,7 @@ def test_vitb16_full_size_fp32_logits_within_1e3():
 @pytest.mark.parametrize("residual", ["fp32", "bf16"])
 def test_vitb16_full_size_bf16_deviation_is_bounded(residual):
     """Perf mode on the real architecture (dino_vitb16 @224, batch 4): the deviation from the
-    fp32 CPU oracle is MEASURED and bounded (logits 3e-2 rel, loss 2e-2, grad norms 8e-2);
+    fp32 CPU oracle is MEASURED and bounded at ~2x the measurement (BF16_TOL above);
     bf16 operands cannot reach the 1e-3 parity bar, which the fp32 mode test above meets."""
     from oracle import vit_ref
     from vit_torch_amd import VisionModelZoo
@@ -183,15 +188,15 @@ def test_vitb16_full_size_bf16_deviation_is_bounded(residual):
     m.load_state_dict(ref.state_dict(), strict=True)
     x, y = data(4, 3, 224, 10)
     out_ref, loss_ref, out, loss, _ = run_step(ref, m, x, y, 10)
-    e = assert_close("vitb16 bf16 logits", out, out_ref, 3e-2)
-    assert abs(loss.item() - loss_ref.item()) < 2e-2
+    e = assert_close("vitb16 bf16 logits", out, out_ref, BF16_TOL[residual][0])
+    assert abs(loss.item() - loss_ref.item()) < BF16_TOL[residual][1]
     worst, worst_name = 0.0, ""
     for (n, pr), (_, pm) in zip(ref.named_parameters(), m.named_parameters()):
         gn_ref, gn = pr.grad.norm().item(), pm.grad.norm().item()
         rel = abs(gn - gn_ref) / max(gn_ref, 1e-12)
         if rel > worst:
             worst, worst_name = rel, n
-    assert worst < 8e-2, f"{worst_name}: {worst}"
+    assert worst < BF16_TOL[residual][2], f"{worst_name}: {worst}"
     print(f"\nvitb16 bf16 (residual {residual}): logits rel err {e:.2e}, loss diff "
           f"{abs(loss.item()-loss_ref.item()):.2e}, worst grad-norm rel {worst:.2e} ({worst_name})")
 

@@ -20,6 +20,7 @@ c_i64, c_i32, c_f32, c_vp, c_sz = C.c_int64, C.c_int32, C.c_float, C.c_void_p, C
 
 class GemmDesc(C.Structure):
     _fields_ = [
+        ("struct_size", c_i64),
         ("M", c_i64), ("N", c_i64), ("K", c_i64),
         ("A", c_vp), ("lda", c_i64), ("a_kmajor", c_i32),
         ("B", c_vp), ("ldb", c_i64), ("b_kmajor", c_i32),
@@ -38,6 +39,10 @@ class GemmDesc(C.Structure):
         ("rowscale", c_vp), ("rows_per_group", c_i64),
         ("colsum_part", c_vp),
     ]
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.struct_size = C.sizeof(GemmDesc)      # the library rejects any other layout
 
 
 # name -> (restype, argtypes); every symbol declared in include/vitmi.h

@@ -960,22 +960,13 @@ extern "C" int vitmi_attn_fwd(const void* qkv, void* out, float* lse, int dtype,
   if (N <= 256 && g_attn_fwd_waves <= 0) {          // whole sequence resident: one workgroup per (image, head)
     const int nwh = attn_waves(N);
     const size_t ldsw = (size_t)nwh * 32 * (hd == 64 ? (AttnCfg<64>::KS + AttnCfg<64>::VS) : (AttnCfg<32>::KS + AttnCfg<32>::VS));
-    static bool attr64 = false, attr32 = false;
     if (hd == 64) {
       auto kern = attn_fwd_whole_kernel<64>;
-      if (!attr64) {
-        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        if (err != hipSuccess) return vitmi_fail((int)err, "attn_fwd: cannot raise dynamic LDS: %s", hipGetErrorString(err));
-        attr64 = true;
-      }
+      if ((rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(kern), 96 * 1024, "attn_fwd"))) return rc;
       hipLaunchKernelGGL(kern, dim3((unsigned)(B * H)), dim3(64 * nwh), ldsw, stream, (const bf16*)qkv, (bf16*)out, lse, (int)N, (int)H, scale * LOG2E);
     } else {
       auto kern = attn_fwd_whole_kernel<32>;
-      if (!attr32) {
-        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        if (err != hipSuccess) return vitmi_fail((int)err, "attn_fwd: cannot raise dynamic LDS: %s", hipGetErrorString(err));
-        attr32 = true;
-      }
+      if ((rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(kern), 96 * 1024, "attn_fwd"))) return rc;
       hipLaunchKernelGGL(kern, dim3((unsigned)(B * H)), dim3(64 * nwh), ldsw, stream, (const bf16*)qkv, (bf16*)out, lse, (int)N, (int)H, scale * LOG2E);
     }
     return vitmi_check_launch("attn_fwd_whole_kernel");
@@ -1039,13 +1030,7 @@ extern "C" int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout
     do {                                                                                                 \
       auto kern = attn_bwd_fused_kernel<HDV, DB>;                                                        \
       const size_t lds = (size_t)nw * 32 * FusedBwdCfg<HDV>::ROW_BYTES;                                  \
-      static bool attr_set = false;                                                                      \
-      if (!attr_set) {                                                                                   \
-        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                        \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);    \
-        if (err != hipSuccess) return vitmi_fail((int)err, "attn_bwd: cannot raise dynamic LDS: %s", hipGetErrorString(err)); \
-        attr_set = true;                                                                                 \
-      }                                                                                                  \
+      if (int rc_ = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024, "attn_bwd")) return rc_; \
       hipLaunchKernelGGL(kern, dim3((unsigned)(B * H)), dim3(64 * nw), lds, stream, (const bf16*)qkv,    \
                          (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, (int)N, (int)H, scale,   \
                          scale * LOG2E, dbias_part, g_attn_dbg);                                         \

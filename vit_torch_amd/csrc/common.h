@@ -19,6 +19,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 void vitmi_set_error(const std::string& s);
 int vitmi_fail(int code, const char* fmt, ...);
 int vitmi_check_launch(const char* what);
+// Per-device facts, filled once per device under a lock (the library's only process-wide
+// state besides the vitmi_debug_* switches): CU count of the current device, and the
+// dynamic-LDS limit of a kernel raised once per (kernel, device).
+int vitmi_cu_count();
+int vitmi_raise_dynamic_lds(const void* kern, int bytes, const char* who);
 // out[c] = sum_{r<S} part[r*ld + c], c < N (elementwise.hip)
 int vitmi_reduce_rows(const float* part, int S, int64_t N, int64_t ld, float* out, hipStream_t stream);
 int vitmi_reduce_rows_segs(const float* part, int S, int64_t ld, float* const out[4], const int width[4],

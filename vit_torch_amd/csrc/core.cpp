@@ -1,6 +1,10 @@
 // Error plumbing + version for libvitmi (host only).
 #include <cstdarg>
 #include <cstdio>
+#include <map>
+#include <mutex>
+#include <set>
+#include <utility>
 #include "common.h"
 
 static thread_local std::string g_last_error;
@@ -22,6 +26,39 @@ int vitmi_check_launch(const char* what) {
   if (err == hipSuccess) return 0;
   g_last_error = std::string(what) + ": " + hipGetErrorString(err);
   return (int)err;
+}
+
+namespace {
+std::mutex g_dev_mu;
+std::map<int, int> g_cus;                              // device -> CU count
+std::set<std::pair<const void*, int>> g_lds_raised;    // (kernel, device)
+int current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  return dev;
+}
+}  // namespace
+
+int vitmi_cu_count() {
+  const int dev = current_device();
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  auto it = g_cus.find(dev);
+  if (it != g_cus.end()) return it->second;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  g_cus[dev] = cus;
+  return cus;
+}
+
+int vitmi_raise_dynamic_lds(const void* kern, int bytes, const char* who) {
+  const int dev = current_device();
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  const auto key = std::make_pair(kern, dev);
+  if (g_lds_raised.count(key)) return 0;
+  hipError_t err = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (err != hipSuccess) return vitmi_fail((int)err, "%s: cannot raise dynamic LDS to %d: %s", who, bytes, hipGetErrorString(err));
+  g_lds_raised.insert(key);
+  return 0;
 }
 
 extern "C" int vitmi_version(void) { return VITMI_VERSION; }

@@ -249,8 +249,11 @@ __global__ __launch_bounds__(256) void xent_kernel(const float* __restrict__ log
     }
   }
   if (lane == 0) {
-    loss_rows[b] = lse - lr[lab];
-    correct_rows[b] = (amax == (int)lab) ? 1 : 0;
+    // a label outside [0, K) must not become an out-of-bounds read: its sample's loss (and
+    // with it the mean) is NaN, which the host sees at the next .item()
+    const bool ok = lab >= 0 && lab < (int64_t)K;
+    loss_rows[b] = ok ? lse - lr[ok ? lab : 0] : __builtin_nanf("");
+    correct_rows[b] = (ok && amax == (int)lab) ? 1 : 0;
   }
 }
 

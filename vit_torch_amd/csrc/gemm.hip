@@ -144,6 +144,9 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs g) {
 
 static int build_args(const vitmi_gemm_desc* d, GemmArgs* out) {
   VITMI_REQUIRE(d, VITMI_E_BADARG, "gemm: null descriptor");
+  VITMI_REQUIRE(d->struct_size == (int64_t)sizeof(vitmi_gemm_desc), VITMI_E_BADARG,
+                "gemm: descriptor struct_size %lld != %lld (caller built against another vitmi.h?)",
+                (long long)d->struct_size, (long long)sizeof(vitmi_gemm_desc));
   VITMI_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, VITMI_E_BADARG, "gemm: M,N,K must be > 0 (got %lld,%lld,%lld)",
                 (long long)d->M, (long long)d->N, (long long)d->K);
   VITMI_REQUIRE(d->A && d->B && d->C, VITMI_E_BADARG, "gemm: A, B, C must be non-null");

@@ -596,8 +596,7 @@ constexpr int TAIL_SPLITS = 3;
 // M x N fp32 slabs (only the tail tiles' part is touched), no fused column sums, and a
 // contraction long enough that a third of it still amortises the partial-tile traffic.
 static bool tail_plan_shape(const GemmArgs& g, int nwg, int* rem, int* splits, int* ksps, bool forced) {
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  const int cus = vitmi_cu_count();
   const int nt = (int)(g.K / BK);
   const int r = nwg % cus;
   if (nwg <= cus || r == 0 || r * TAIL_SPLITS > cus) return false;
@@ -650,12 +649,7 @@ int launch_p(const GemmArgs& g, hipStream_t stream) {
     splitk_plan(nwg, (int)(g.K / BK), &splits, &ksps);
     if (splits > 1 && g.ws && g.ws_bytes >= (size_t)splits * g.M * g.N * sizeof(float)) {
       auto kern = gemm_fast_kernel<A_KM, B_KM, MODE, TC, true, PIPE>;
-      static bool attr_set_sk = false;
-      if (!attr_set_sk) {
-        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-        if (err != hipSuccess) return vitmi_fail((int)err, "gemm_fast: cannot raise dynamic LDS: %s", hipGetErrorString(err));
-        attr_set_sk = true;
-      }
+      if (int rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(kern), 2 * STAGE_BYTES, "gemm_fast(split-K)")) return rc;
       float* ws = reinterpret_cast<float*>(g.ws);
       hipLaunchKernelGGL(kern, dim3(nwg * splits), dim3(NTHREADS), 2 * STAGE_BYTES, stream, g, tiles_n, nwg * splits, nwg, ksps, ws, 0);
       int rc = vitmi_check_launch("gemm_fast_kernel(split-K)");
@@ -677,13 +671,8 @@ int launch_p(const GemmArgs& g, hipStream_t stream) {
       const int full = nwg - rem;
       auto kmain = gemm_fast_kernel<A_KM, B_KM, MODE, TC, false, PIPE>;
       auto ktail = gemm_fast_kernel<A_KM, B_KM, VITMI_EPI_STORE, float, true, PIPE>;
-      static bool attr_tail = false;
-      if (!attr_tail) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(kmain), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(ktail), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-        if (e1 != hipSuccess || e2 != hipSuccess) return vitmi_fail((int)(e1 != hipSuccess ? e1 : e2), "gemm_fast: cannot raise dynamic LDS");
-        attr_tail = true;
-      }
+      if (int rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(kmain), 2 * STAGE_BYTES, "gemm_fast")) return rc;
+      if (int rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(ktail), 2 * STAGE_BYTES, "gemm_fast(tail)")) return rc;
       float* ws = reinterpret_cast<float*>(g.ws);
       hipLaunchKernelGGL(kmain, dim3(full), dim3(NTHREADS), 2 * STAGE_BYTES, stream, g, tiles_n, full, full, 0, (float*)nullptr, 0);
       int rc = vitmi_check_launch("gemm_fast_kernel(full rounds)");
@@ -695,12 +684,7 @@ int launch_p(const GemmArgs& g, hipStream_t stream) {
     }
   }
   auto kern = gemm_fast_kernel<A_KM, B_KM, MODE, TC, false, PIPE>;
-  static bool attr_set = false;   // per instantiation
-  if (!attr_set) {
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    if (err != hipSuccess) return vitmi_fail((int)err, "gemm_fast: cannot raise dynamic LDS to %d: %s", 2 * STAGE_BYTES, hipGetErrorString(err));
-    attr_set = true;
-  }
+  if (int rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(kern), 2 * STAGE_BYTES, "gemm_fast")) return rc;
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(NTHREADS), 2 * STAGE_BYTES, stream, g, tiles_n, nwg, nwg, 0, (float*)nullptr, 0);
   return vitmi_check_launch("gemm_fast_kernel");
 }

@@ -372,12 +372,7 @@ int launch2(const GemmArgs& g, hipStream_t stream) {
     splitk_plan2(nwg, (int)(g.K / BK2), &splits, &ksps);
     if (splits > 1 && g.ws && g.ws_bytes >= (size_t)splits * g.M * g.N * sizeof(float)) {
       auto kern = gemm_fast2_kernel<A_KM, B_KM, MODE, TC, true>;
-      static bool attr_sk = false;
-      if (!attr_sk) {
-        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
-        if (err != hipSuccess) return vitmi_fail((int)err, "gemm_fast2: cannot raise dynamic LDS: %s", hipGetErrorString(err));
-        attr_sk = true;
-      }
+      if (int rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(kern), LDS2, "gemm_fast2(split-K)")) return rc;
       float* ws = reinterpret_cast<float*>(g.ws);
       hipLaunchKernelGGL(kern, dim3(nwg * splits), dim3(NT2), LDS2, stream, g, tiles_n, nwg * splits, nwg, ksps, ws);
       int rc = vitmi_check_launch("gemm_fast2_kernel(split-K)");
@@ -391,12 +386,7 @@ int launch2(const GemmArgs& g, hipStream_t stream) {
     }
   }
   auto kern = gemm_fast2_kernel<A_KM, B_KM, MODE, TC, false>;
-  static bool attr = false;
-  if (!attr) {
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
-    if (err != hipSuccess) return vitmi_fail((int)err, "gemm_fast2: cannot raise dynamic LDS: %s", hipGetErrorString(err));
-    attr = true;
-  }
+  if (int rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(kern), LDS2, "gemm_fast2")) return rc;
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(NT2), LDS2, stream, g, tiles_n, nwg, nwg, 0, (float*)nullptr);
   return vitmi_check_launch("gemm_fast2_kernel");
 }

@@ -295,11 +295,7 @@ int gemm_small_launch(const GemmArgs& g, int form, hipStream_t stream) {
   a.alpha = g.e.alpha;
   const size_t lds = small_lds(form, a.M, a.N, a.K);
   // fewer than four workgroups per CU: split the row tiles of a problem over two workgroups
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-  }
+  const int cus = vitmi_cu_count();
   const int tiles_m = (a.M + 15) / 16;
   // (measured at 512 problems of 196 x 196 x 48: form 0 22.3 -> 20.3 us, form 1 22.1 -> 16.7;
   // form 2 streams S through LDS once per workgroup, so a second one doubles that: 24.5 -> 35.9)
@@ -309,13 +305,7 @@ int gemm_small_launch(const GemmArgs& g, int form, hipStream_t stream) {
 #define SMALL_GO(F)                                                                                   \
   do {                                                                                                \
     auto kern = gemm_small_kernel<F>;                                                                 \
-    static bool attr = false;                                                                         \
-    if (!attr) {                                                                            \
-      hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);    \
-      if (err != hipSuccess) return vitmi_fail((int)err, "gemm_small: cannot raise dynamic LDS: %s", hipGetErrorString(err)); \
-      attr = true;                                                                                    \
-    }                                                                                                 \
+    if (int rc_ = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(kern), 96 * 1024, "gemm_small")) return rc_; \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);                                        \
   } while (0)
   if (form == 0) SMALL_GO(0);

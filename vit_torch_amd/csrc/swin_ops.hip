@@ -740,12 +740,7 @@ extern "C" int vitmi_win_attn_bwd(const void* qkv, const void* dout, const float
     if (per_head < 1) per_head = 1;
     const int nwaves = (int)(per_head * H);
     auto kern = win_attn_bwd_mfma_kernel;
-    static bool attr = false;
-    if (!attr) {
-      hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WIN_BWD_LDS);
-      if (err != hipSuccess) return vitmi_fail((int)err, "win_attn_bwd: cannot raise dynamic LDS: %s", hipGetErrorString(err));
-      attr = true;
-    }
+    if ((rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(kern), 4 * WIN_BWD_LDS, "win_attn_bwd"))) return rc;
     float* qb_part = dqkv_bias ? part + per_head * H * N * N : nullptr;     // [per_head][3*H*32]
     hipLaunchKernelGGL(kern, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 4 * WIN_BWD_LDS, stream, (const bf16*)qkv,
                        (const bf16*)dout, lse, bias, mask, (bf16*)dqkv, part, qb_part, g, (int)H, (int)N, scale, Bw, nwaves);

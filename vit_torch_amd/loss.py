@@ -12,6 +12,9 @@ from . import ops
 class _XentFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, labels, owner):
+        if labels.dtype != torch.int64 or labels.dim() != 1 or labels.shape[0] != logits.shape[0]:
+            raise TypeError(f"CrossEntropyLoss: labels must be int64 [B] class indices, got {labels.dtype} "
+                            f"{tuple(labels.shape)} for logits {tuple(logits.shape)}")
         B, K = logits.shape
         lg = logits.contiguous().float()
         loss_buf = torch.empty(1 + B, dtype=torch.float32, device=lg.device)

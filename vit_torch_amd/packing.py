@@ -57,24 +57,38 @@ class ParamPack:
     def g(self, p) -> torch.Tensor:
         return self._slice(self.grad, p)
 
-    # ---- bf16 shadow freshness: torch bumps the flat buffer's version counter on every
-    # in-place write through it or any view (optimizer updates, load_state_dict, init);
-    # our own kernels write through raw pointers and report what they refreshed
+    # ---- bf16 shadow freshness.  The shadow is trusted only while nothing torch can see has
+    # written a parameter since the last cast / fused-optimizer pass: every Parameter keeps its
+    # OWN version counter (`p.data = view` does not tie it to the flat buffer's), so the key
+    # covers the flat buffer and every parameter: p.add_(), torch.optim steps,
+    # load_state_dict(), nn.init all bump one of them.  Our own kernels write through raw
+    # pointers and report what they refreshed (mark_shadow_current).  Writes through a
+    # detached alias (`p.data.copy_()`) carry a fresh counter nobody can observe: call
+    # invalidate_shadow() after those.
+    def _version_key(self):
+        return (self.flat._version, sum(p._version for p in self.params))
+
     def refresh_shadow(self) -> None:
-        """Cast fp32 -> bf16 unless the shadow already mirrors the current master values."""
+        """Cast fp32 -> bf16 unless the shadow provably mirrors the current master values."""
         if self.shadow is None:
             return
-        v = self.flat._version
+        key = self._version_key()
         # inside a graph capture the cast is always recorded: a replay then re-derives the
         # shadow from whatever the master holds (weights loaded between replays stay correct)
-        if getattr(self, "_shadow_version", None) != v or torch.cuda.is_current_stream_capturing():
+        if getattr(self, "_shadow_key", None) != key or torch.cuda.is_current_stream_capturing():
             from . import ops
             ops.cast(self.flat, self.shadow)
-            self._shadow_version = v
+            self._shadow_key = key
 
     def mark_shadow_current(self) -> None:
-        """Called by a kernel that rewrote master AND shadow together (FusedSGD)."""
-        self._shadow_version = self.flat._version
+        """Called by a kernel that rewrote master AND shadow together over some span (FusedSGD,
+        FusedAdamW).  Such kernels write through raw pointers, so no version torch can see moved:
+        the key still matches exactly when the shadow was current before the pass, and a
+        pending outside write (another parameter changed through torch) stays pending."""
+        return None
+
+    def invalidate_shadow(self) -> None:
+        self._shadow_key = None
 
     def w(self, p) -> torch.Tensor:
         """GEMM-operand view: bf16 shadow when there is one, else the fp32 master."""
@@ -99,3 +113,17 @@ class ParamPack:
         last = idx[-1]
         end = self.offsets[last] + _round_up(self.params[last].numel())
         return start, end
+
+    def runs(self, params) -> List[Tuple[int, int]]:
+        """Maximal contiguous [start, end) element ranges of the flat buffers that cover exactly
+        `params` (parameters adjacent in pack order are adjacent in memory, padding included)."""
+        idx = sorted({self.index[id(p)] for p in params})
+        out: List[Tuple[int, int]] = []
+        for i in idx:
+            start = self.offsets[i]
+            end = start + _round_up(self.params[i].numel())
+            if out and out[-1][1] == start:
+                out[-1] = (out[-1][0], end)
+            else:
+                out.append((start, end))
+        return out
