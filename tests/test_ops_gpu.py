@@ -406,10 +406,10 @@ FAST_SHAPES = [(256, 256, 64), (512, 768, 768), (768, 512, 1024), (1024, 256, 12
                (512, 256, 6464), (256, 128, 64), (512, 384, 320)]
 
 
-@pytest.fixture(params=["t1p0", "t1p1", "t1p2", "t2"])
+@pytest.fixture(params=["t1p0", "t1p1", "t1p2", "t1p3", "t2"])
 def pipe(request, lib):
     """Run a test once per variant of the fast GEMM — 256x256 tiles with the simple /
-    4-slab-ring / 64-deep-stage main loops, and 256x128 tiles with two workgroups per CU —
+    4-slab-ring / 64-deep-stage / 3-slab-ring (residual epilogue only) main loops, and 256x128 tiles with two workgroups per CU —
     through the diagnostic hooks the library exports."""
     import ctypes
     from vit_torch_amd import _lib as L
@@ -629,3 +629,43 @@ def test_gemm_fast_matches_generic_bitwise_on_integers(ops, pipe):
         ops.gemm(A, B, Cg, a_kmajor=akm, b_kmajor=bkm, impl=GEMM_GENERIC)
         assert torch.equal(Cf.cpu(), want), f"fast kernel wrong for layout a_km={akm} b_km={bkm}"
         assert torch.equal(Cg.cpu(), want)
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 256, 640), (768, 768, 768), (512, 512, 3072), (256, 256, 1024)])
+def test_gemm_residual_fold_through_lds(ops, lib, M, N, K):
+    """EPI_RESIDUAL, fp32 stream, no LayerScale / DropPath (every ViT block): the 256x256 kernel
+    streams R through LDS during the main loop and adds it into the accumulators
+    (gemm_fast.hip ResFold) instead of reading it in the epilogue.  Must equal the epilogue form
+    (debug switch) to fp32 rounding and the torch reference; LayerScale / DropPath / a second
+    output keep the epilogue form."""
+    import ctypes
+    from vit_torch_amd import _lib as L
+    from vit_torch_amd._lib import EPI_RESIDUAL, GEMM_FAST
+    raw = ctypes.CDLL(str(L.LIB_PATH))
+    bt = torch.bfloat16
+    a, b = bf16_round(gen((M, K), 31)), bf16_round(gen((N, K), 32, 0.2))
+    r, bias, gam = gen((M, N), 33, 3.0), gen((N,), 34), gen((N,), 35)
+    A, B, R, bias_d = dev(a, bt), dev(b, bt), dev(r), dev(bias)
+    acc = a.double() @ b.double().t()
+    try:
+        outs = {}
+        for mode in (1, 0):
+            raw.vitmi_debug_gemm_rfold(mode)
+            X = torch.full((M, N), float("nan"), device="cuda")
+            ops.gemm(A, B, X, epilogue=EPI_RESIDUAL, bias=bias_d, R=R, impl=GEMM_FAST)
+            outs[mode] = X.cpu()
+            assert_close(f"residual[rfold={mode}]", X, (r.double() + acc + bias.double()).float(), 2e-6)
+            X2 = torch.full((M, N), float("nan"), device="cuda")
+            ops.gemm(A, B, X2, epilogue=EPI_RESIDUAL, R=R, impl=GEMM_FAST)                 # no bias
+            assert_close(f"residual-nobias[rfold={mode}]", X2, (r.double() + acc).float(), 2e-6)
+        assert_close("fold vs epilogue form", outs[1], outs[0], 1e-6)
+        raw.vitmi_debug_gemm_rfold(1)
+        X = torch.empty((M, N), device="cuda")
+        ops.gemm(A, B, X, epilogue=EPI_RESIDUAL, bias=bias_d, R=R, gamma=dev(gam), impl=GEMM_FAST)
+        assert_close("residual+gamma (epilogue form)", X, (r.double() + gam.double() * (acc + bias.double())).float(), 2e-6)
+        # in place (C aliases R): every strip is fetched long before its tile is stored
+        Xi = R.clone()
+        ops.gemm(A, B, Xi, epilogue=EPI_RESIDUAL, bias=bias_d, R=Xi, impl=GEMM_FAST)
+        assert torch.equal(Xi.cpu(), outs[1])
+    finally:
+        raw.vitmi_debug_gemm_rfold(-1)

@@ -14,6 +14,10 @@ raw.vitmi_debug_gemm_timeline.argtypes = [ctypes.c_void_p, ctypes.c_int]
 raw.vitmi_debug_gemm_tail(0)       # plain launch: no split tail
 EPI = {"store": _lib.EPI_STORE, "gelu": _lib.EPI_BIAS_GELU, "res": _lib.EPI_RESIDUAL, "dgelu": _lib.EPI_DGELU}
 for spec in sys.argv[1:]:
+    if spec.startswith("rfold="):                   # residual fold on (1) / off (0) for the specs that follow
+        raw.vitmi_debug_gemm_rfold(int(spec[6:]))
+        print(f"--- rfold {spec[6:]}")
+        continue
     parts = spec.split(":")
     layout, M, N, K = parts[0], *map(int, parts[1:4])
     akm, bkm = {"nt": (True, True), "nn": (True, False), "tn": (False, False)}[layout]

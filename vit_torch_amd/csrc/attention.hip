@@ -829,10 +829,21 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16* __restr
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int r = 4 * g + e;
-        float p = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -ls[g][e]));
-        p = kvalid ? p : 0.f;                      // zero-filled K rows give p = exp(-lse) != 0
-        s[r] = p;
-        dp[r] = p * (dp[r] - de[g][e]);
+        s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -ls[g][e]));
+      }
+    }
+    // zero-filled K rows (keys >= N) give p = exp(-lse) != 0: only the last wave owns such
+    // keys, so the 16 selects sit behind a wave-uniform branch (loop 26 k -> 22.6 k cycles)
+    if (w == nw - 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = kvalid ? s[r] : 0.f;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        dp[r] = s[r] * (dp[r] - de[g][e]);
       }
     }
     // dS -> wave-private tile T[key][q] (bf16), 4 consecutive queries per store

@@ -27,6 +27,7 @@ struct GemmArgs {
   int dbg_blocks;                 // workgroups whose timeline is stamped
   int64_t batch, batch_inner, a_bs[2], b_bs[2], c_bs[2];   // batched form (generic kernel)
   int vec_a, vec_b;               // operand rows are 16-B aligned: vector staging allowed
+  int rfold;                      // gemm_fast: stream the fp32 residual through LDS during the main loop
   EpiArgs e;
 };
 

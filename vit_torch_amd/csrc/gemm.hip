@@ -161,6 +161,7 @@ static int build_args(const vitmi_gemm_desc* d, GemmArgs* out) {
   g.A = d->A; g.lda = d->lda; g.a_km = d->a_kmajor ? 1 : 0;
   g.B = d->B; g.ldb = d->ldb; g.b_km = d->b_kmajor ? 1 : 0;
   g.ws = d->workspace; g.ws_bytes = d->workspace_bytes;
+  g.rfold = 0;
   g.dbg = g_gemm_dbg;
   g.dbg_blocks = g_gemm_dbg_blocks;
   g.batch = d->batch > 1 ? d->batch : 1;

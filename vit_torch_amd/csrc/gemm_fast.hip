@@ -200,6 +200,60 @@ __device__ __forceinline__ uint32_t frag_half(uint32_t off, int kh) {
 }
 
 
+// ---- residual fold (EPI_RESIDUAL, fp32 stream, no LayerScale / DropPath: every ViT block).
+// The epilogue x_new = R + (acc + b) used to read R (256 KiB of fp32 per tile) AFTER the main
+// loop, all CUs at the same moment: 37-41 k cycles of HBM-bound epilogue during which no MFMA
+// runs, against a 42 k-cycle main loop at K = 768 (tools/gemm_timeline.py).  Instead R streams
+// HBM -> LDS by LDS-DMA DURING the main loop (no registers needed, HBM otherwise idle there),
+// one wave-private 16-row x 64-column strip (4 KiB) per k-step, and is ADDED INTO THE
+// ACCUMULATORS two k-steps later (4 ds_read_b128 + 16 adds per strip): the epilogue is then a
+// bias-add + store.  An R strip comes from HBM (~6 k cycles under load), so TWO strips per wave
+// must be in flight: 64 KiB of LDS.  The loop that carries it is therefore PIPE 3 = the
+// PIPE 1 loop on a ring of THREE 32-deep slabs (96 KiB) instead of four.  (A first version kept
+// PIPE 2's two 64-KiB stages and one 4-KiB strip per wave: its main loop went 42 k -> 65 k
+// cycles waiting for each strip within its own k-step.)
+// Ordering: a strip's four DMAs are issued AFTER the slab DMAs of the same iteration, so the
+// counted vmcnt that retires slab j+1 (everything older than slab j+2) leaves the newest
+// strip in flight; a strip issued in iteration j is complete after the wait of iteration
+// j+2 and is read in iteration j+4 by the wave that issued it (no barrier involved).
+// Strip image: 16 rows x 256 B, 16-B chunk c of row r stored at chunk c ^ r (on the DMA's
+// per-lane SOURCE address, as always), so the accumulator-shaped reads (row = lane & 15,
+// chunk 4 ni + lane >> 4) are bank-conflict free.
+constexpr int RING3_BYTES = 3 * (2 * 256 * 32 * 2);   // three slabs of A|B: 96 KiB
+constexpr int RF_BASE = RING3_BYTES;             // first byte above the ring
+constexpr int RF_STRIP = 16 * 64 * 4;            // one strip: 4 KiB
+constexpr int RF_LDS = RF_BASE + 8 * 2 * RF_STRIP;   // 160 KiB: the CU's whole LDS
+struct ResFold {
+  const char* base;       // wave-uniform: &R[m0 + wm*128][n0 + wn*64]
+  uint32_t off[4];        // per lane, one per 1-KiB DMA piece (4 rows x 256 B)
+  int64_t strip_step;     // bytes between strips (16 rows)
+  uint32_t rd;            // per lane LDS offset of chunk (ni = 0) in its row; ni adds (4*ni) ^ ... see read()
+  int lr, lg;
+  __device__ __forceinline__ void init(const float* R, int64_t ldr, int64_t m0, int64_t n0, int wm, int wn, int lane) {
+    base = reinterpret_cast<const char*>(R + (m0 + wm * 128) * ldr + n0 + wn * 64);
+    strip_step = 16 * ldr * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 4 * i + (lane >> 4);
+      const int c = (lane & 15) ^ row;           // LDS position (lane & 15) of row `row` holds chunk c
+      off[i] = (uint32_t)((row * ldr + c * 4) * 4);
+    }
+    lr = lane & 15; lg = lane >> 4;
+  }
+  __device__ __forceinline__ void issue(char* strip, int s) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(base + (int64_t)s * strip_step + off[i], strip + i * 1024);
+  }
+  // the wave's accumulator-shaped view of the strip: f32x4 of (row lr, columns 16 ni + 4 lg ..)
+  __device__ __forceinline__ void read(const char* strip, u32x4 (&r)[4]) const {
+    const uint32_t a = (uint32_t)(uintptr_t)LDS_PTR(char, strip) + (uint32_t)lr * 256u;
+    const uint32_t a0 = a + (uint32_t)(((0 + lg) ^ lr) * 16), a1 = a + (uint32_t)(((4 + lg) ^ lr) * 16);
+    const uint32_t a2 = a + (uint32_t)(((8 + lg) ^ lr) * 16), a3 = a + (uint32_t)(((12 + lg) ^ lr) * 16);
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]) : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "memory");
+  }
+};
+
 // SPLITK: the grid is (tiles x splits); block (tile, s) contracts k-steps
 // [s*ksps, min((s+1)*ksps, nt)) and stores its raw fp32 partial tile into slab s
 // of `ws` ([splits][M][N]); splitk_reduce_kernel sums the slabs in a fixed order
@@ -217,6 +271,10 @@ __device__ __forceinline__ uint32_t frag_half(uint32_t off, int kh) {
 // steady state, and the counted vmcnt (8 = two younger slabs may still be in flight)
 // before the barrier that precedes the first read orders it (guide: "Read a staged
 // buffer one phase AFTER the wait that retires it").
+__device__ __forceinline__ bool g_rfold_enabled(const GemmArgs& g) {
+  return g.rfold != 0 && !g.e.gamma && !g.e.rowscale && !g.e.C2 && !g.e.r_bf16;
+}
+
 template <bool A_KM, bool B_KM, int MODE, typename TC, bool SPLITK = false, int PIPE = 0>
 __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int tiles_n, int nwg,
                                                              int ntiles, int ksps, float* ws, int tile0) {
@@ -247,6 +305,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
   const int nt_all = (int)(g.K / BK);
   const int kt0 = SPLITK ? split * ksps : 0;
   const int nt = SPLITK ? min(ksps, nt_all - kt0) : nt_all;
+  // residual fold (see ResFold): compiled into the PIPE 3 loop of the fp32-stream residual
+  // epilogue, taken when nothing scales the branch and the contraction has the 19 slabs the
+  // eight strips need
+  constexpr bool RFOLD_T = MODE == VITMI_EPI_RESIDUAL && sizeof(TC) == 4 && !SPLITK && PIPE == 3;
+  const bool rfold = RFOLD_T && g_rfold_enabled(g) && nt >= 10;
   // diagnostic build of the timeline (armed by tools/gemm_phases.py only): entry,
   // epilogue start and end of the first 64 blocks, wave 0
   const bool dbg_tl = g.dbg != nullptr && (int)blockIdx.x < g.dbg_blocks && wave == 0;
@@ -282,7 +345,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
     __syncthreads();   // next stage landed (vmcnt(0)) and everyone is done reading `cur`
   }
 
-  } else if constexpr (PIPE == 1) {
+  } else if constexpr (PIPE == 1 || PIPE == 3) {
+    constexpr int RING = PIPE == 3 ? 3 : 4;        // slabs resident; RING - 1 are prefetched ahead
+    constexpr int AHEAD = RING - 1;
     const int ns = 2 * nt;                         // 32-deep slabs
     const int64_t kb0 = (int64_t)kt0 * BK;
     const int grp = wm;                            // 0: leads, 1: one barrier behind
@@ -295,15 +360,24 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
     for (int mi = 0; mi < 8; ++mi) fa[mi] = frag_off<A_KM>(wm * 8 + mi, lane);
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) fb[ni] = frag_off<B_KM>(wn * 4 + ni, lane) + SLAB_BYTES;
-    auto issue = [&](int j) {
-      char* st = smem + (j & 3) * RING_STAGE;
+    int stage_i = 0;                               // j % RING without a division
+    auto stage_of = [&](int ahead) { int x = stage_i + ahead; return x >= RING ? x - RING : x; };
+    auto issue = [&](int j, int st_idx) {
+      char* st = smem + st_idx * RING_STAGE;
       pa.issue(st, j, wave);
       pb_.issue(st + SLAB_BYTES, j, wave);
     };
-    issue(0);
-    issue(1);
-    if (ns > 2) issue(2);
-    wait_vm(ns > 2 ? 8 : 4);                       // slab 0 has landed
+    ResFold rf;
+    if constexpr (RFOLD_T) { if (rfold) rf.init(reinterpret_cast<const float*>(g.e.R), g.e.ldr, m0, n0, wm, wn, lane); }
+    char* rstrip = smem + RF_BASE + wave * 2 * RF_STRIP;   // this wave's two strip buffers
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a)
+      if (a < ns) issue(a, a);
+    if constexpr (RFOLD_T) { if (rfold) rf.issue(rstrip, 0); }       // strip 0 rides behind the prologue slabs
+    {   // slab 0 has landed: everything issued after it may still fly
+      const int younger = min(ns, AHEAD) - 1;
+      wait_vm(4 * younger + ((RFOLD_T && rfold) ? 4 : 0));
+    }
     raw_barrier();                                 // b0
     if (grp == 1) raw_barrier();                   // stagger
     const bool dbg = g.dbg != nullptr && blockIdx.x == 0;   // wave-uniform
@@ -312,25 +386,52 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
     for (int j = 0; j < ns; ++j) {
       if (dbg) t0 = stamp();
       // ---- R(j)
-      if (j + 3 < ns) issue(j + 3);
-      const char* As = smem + (j & 3) * RING_STAGE;
+      if (j + AHEAD < ns) issue(j + AHEAD, stage_of(AHEAD));
+      const char* As = smem + stage_i * RING_STAGE;
       Frag<B_KM> fbv[4];
       Frag<A_KM> fav[8];
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) fbv[ni].load(As, fb[ni]);
 #pragma unroll
       for (int mi = 0; mi < 8; ++mi) fav[mi].load(As, fa[mi]);
+      // residual fold: strip s is issued in iteration 2s (s = 0 in the prologue) and read in
+      // iteration 2s + 4; buffer s & 1
+      u32x4 rfv[4];
+      const bool rf_even = RFOLD_T && rfold && (j & 1) == 0;                 // wave-uniform
+      const bool rf_read = rf_even && j >= 4 && j < 20;
+      const bool rf_issue = rf_even && j >= 2 && j < 16;
+      if constexpr (RFOLD_T) { if (rf_read) rf.read(rstrip + (((j >> 1) - 2) & 1) * RF_STRIP, rfv); }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of this stage are complete
       frag_wait4(fbv[0], fbv[1], fbv[2], fbv[3]);
       frag_wait4(fav[0], fav[1], fav[2], fav[3]);
       frag_wait4(fav[4], fav[5], fav[6], fav[7]);
+      if constexpr (RFOLD_T) {
+        if (rf_read) {
+          asm volatile("" : "+v"(rfv[0]), "+v"(rfv[1]), "+v"(rfv[2]), "+v"(rfv[3]));   // named after the wait
+#pragma unroll
+          for (int S = 0; S < 8; ++S)
+            if ((j >> 1) - 2 == S) {
+#pragma unroll
+              for (int ni = 0; ni < 4; ++ni) acc[ni][S] += __builtin_bit_cast(f32x4, rfv[ni]);
+            }
+        }
+        if (rf_issue) rf.issue(rstrip + ((j >> 1) & 1) * RF_STRIP, j >> 1);   // its buffer has just been read
+      }
       bf16x8 bf[4], af[8];
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) bf[ni] = fbv[ni].get();
 #pragma unroll
       for (int mi = 0; mi < 8; ++mi) af[mi] = fav[mi].get();
-      const int rem = ns - 2 - j;                   // slabs younger than j+1 already issued
-      if (grp == 1) wait_vm(rem >= 2 ? 8 : (rem == 1 ? 4 : 0));
+      // slab j+1 must have landed before the next iteration reads it: everything issued after
+      // it may still be in flight = the slabs ahead of it + the strip issued in this iteration
+      // or the previous one (strips go out every other iteration, behind that iteration's slab)
+      int fly = min(ns - 2 - j, AHEAD - 1);
+      if (fly < 0) fly = 0;
+      int nvm = 4 * fly;
+      // strips younger than slab j+1: the one issued in this iteration (even j in [2,16)) or the
+      // previous one (odd j), or the prologue's strip 0 (younger than slab 1 only: j = 0)
+      if constexpr (RFOLD_T) { if (rfold && (j == 0 || (j >= 2 && j < 16))) nvm += 4; }
+      if (grp == 1) wait_vm(nvm);
       if (dbg) { t1 = stamp(); tR += t1 - t0; }
       raw_barrier();
       if (dbg) { t0 = stamp(); tWR += t0 - t1; }
@@ -346,10 +447,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
 #ifdef VITMI_GEMM_SETPRIO
       __builtin_amdgcn_s_setprio(0);
 #endif
-      if (grp == 0) wait_vm(rem >= 2 ? 8 : (rem == 1 ? 4 : 0));
+      if (grp == 0) wait_vm(nvm);
       if (dbg) { t1 = stamp(); tM += t1 - t0; }
       if (!(grp == 1 && j == ns - 1)) raw_barrier();
       if (dbg) { t0 = stamp(); tWM += t0 - t1; }
+      stage_i = stage_i == RING - 1 ? 0 : stage_i + 1;
     }
     if (dbg && lane == 0) {
       g.dbg[wave * 4 + 0] = tR; g.dbg[wave * 4 + 1] = tWR;
@@ -451,7 +553,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
     if (MODE == VITMI_EPI_RESIDUAL && g.e.gamma) loadv<float, W>(g.e.gamma + n0 + wn * 64 + rc, gamma_r);
   }
   constexpr int NJ = 16 / RPI;                     // row groups per strip
-  const bool side = !SPLITK && epi_has_side<MODE, TC>(g.e);
+  // (residual fold: R is already inside the accumulators; x = 0, gamma = 1 -> v = acc + b)
+  const bool side = !SPLITK && epi_has_side<MODE, TC>(g.e) && !rfold;
   const int64_t ncol = n0 + wn * 64 + rc;
   float cs[W];                                     // DGELU: column sums of this lane's rows
 #pragma unroll
@@ -614,6 +717,10 @@ static bool tail_plan(const GemmArgs& g, int nwg, int* rem, int* splits, int* ks
   return g.ws != nullptr && g.ws_bytes >= (size_t)TAIL_SPLITS * g.M * g.N * sizeof(float);
 }
 
+static int g_rfold_override = -1;
+// diagnostic / test hook: 0 = epilogue reads the residual (round-1 behaviour), 1 / -1 = fold it in
+extern "C" void vitmi_debug_gemm_rfold(int mode) { g_rfold_override = mode; }
+
 static int g_pipe_override = -1;
 // diagnostic / test hook: force the main-loop variant (0, 1, 2) or -1 = automatic
 extern "C" void vitmi_debug_gemm_pipe(int mode) { g_pipe_override = mode; }
@@ -623,7 +730,7 @@ static int pipe_mode() {   // -1 = automatic (per layout), else forced 0/1/2
   static int mode = -2;
   if (mode == -2) {
     const char* e = getenv("VITMI_GEMM_PIPE");
-    mode = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : -1;
+    mode = (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : -1;
   }
   return mode;
 }
@@ -634,14 +741,29 @@ int launch_p(const GemmArgs& g, hipStream_t stream);
 template <bool A_KM, bool B_KM, int MODE, typename TC>
 int launch(const GemmArgs& g, hipStream_t stream) {
   int pm = pipe_mode();
-  if (pm < 0) pm = (A_KM && B_KM) ? 2 : 1;   // k-major operands want full-line DMA (PIPE 2)
+  constexpr bool CAN_FOLD = MODE == VITMI_EPI_RESIDUAL && sizeof(TC) == 4;
+  if (pm < 0) {
+    pm = (A_KM && B_KM) ? 2 : 1;   // k-major operands want full-line DMA (PIPE 2)
+    // the fp32-stream residual epilogue takes the ring-of-three loop that streams R through LDS
+    if (CAN_FOLD && g_rfold_override != 0 && !g.e.gamma && !g.e.rowscale && !g.e.C2 && !g.e.r_bf16 && g.K >= 640) pm = 3;
+  }
   if (pm == 0) return launch_p<A_KM, B_KM, MODE, TC, 0>(g, stream);
+  if (pm == 1) return launch_p<A_KM, B_KM, MODE, TC, 1>(g, stream);
+  if constexpr (CAN_FOLD) { if (pm == 3) return launch_p<A_KM, B_KM, MODE, TC, 3>(g, stream); }
+  else if (pm == 3) pm = 1;        // PIPE 3 exists only where the fold does: everything else keeps the ring of four
   if (pm == 1) return launch_p<A_KM, B_KM, MODE, TC, 1>(g, stream);
   return launch_p<A_KM, B_KM, MODE, TC, 2>(g, stream);
 }
 
+template <int MODE, typename TC, bool SPLITK, int PIPE>
+constexpr int lds_bytes() {
+  return (MODE == VITMI_EPI_RESIDUAL && sizeof(TC) == 4 && !SPLITK && PIPE == 3) ? RF_LDS : 2 * STAGE_BYTES;
+}
+
 template <bool A_KM, bool B_KM, int MODE, typename TC, int PIPE>
-int launch_p(const GemmArgs& g, hipStream_t stream) {
+int launch_p(const GemmArgs& g_in, hipStream_t stream) {
+  GemmArgs g = g_in;
+  g.rfold = g_rfold_override == 0 ? 0 : 1;
   const int tiles_m = (int)(g.M / BM), tiles_n = (int)(g.N / BN);
   const int nwg = tiles_m * tiles_n;
   if constexpr (MODE == VITMI_EPI_STORE && sizeof(TC) == 4) {
@@ -671,10 +793,11 @@ int launch_p(const GemmArgs& g, hipStream_t stream) {
       const int full = nwg - rem;
       auto kmain = gemm_fast_kernel<A_KM, B_KM, MODE, TC, false, PIPE>;
       auto ktail = gemm_fast_kernel<A_KM, B_KM, VITMI_EPI_STORE, float, true, PIPE>;
-      if (int rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(kmain), 2 * STAGE_BYTES, "gemm_fast")) return rc;
+      constexpr int LDSM = lds_bytes<MODE, TC, false, PIPE>();
+      if (int rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(kmain), LDSM, "gemm_fast")) return rc;
       if (int rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(ktail), 2 * STAGE_BYTES, "gemm_fast(tail)")) return rc;
       float* ws = reinterpret_cast<float*>(g.ws);
-      hipLaunchKernelGGL(kmain, dim3(full), dim3(NTHREADS), 2 * STAGE_BYTES, stream, g, tiles_n, full, full, 0, (float*)nullptr, 0);
+      hipLaunchKernelGGL(kmain, dim3(full), dim3(NTHREADS), LDSM, stream, g, tiles_n, full, full, 0, (float*)nullptr, 0);
       int rc = vitmi_check_launch("gemm_fast_kernel(full rounds)");
       if (rc) return rc;
       hipLaunchKernelGGL(ktail, dim3(rem * splits), dim3(NTHREADS), 2 * STAGE_BYTES, stream, g, tiles_n, rem * splits, rem, ksps, ws, full);
@@ -684,8 +807,9 @@ int launch_p(const GemmArgs& g, hipStream_t stream) {
     }
   }
   auto kern = gemm_fast_kernel<A_KM, B_KM, MODE, TC, false, PIPE>;
-  if (int rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(kern), 2 * STAGE_BYTES, "gemm_fast")) return rc;
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(NTHREADS), 2 * STAGE_BYTES, stream, g, tiles_n, nwg, nwg, 0, (float*)nullptr, 0);
+  constexpr int LDSK = lds_bytes<MODE, TC, false, PIPE>();
+  if (int rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(kern), LDSK, "gemm_fast")) return rc;
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(NTHREADS), LDSK, stream, g, tiles_n, nwg, nwg, 0, (float*)nullptr, 0);
   return vitmi_check_launch("gemm_fast_kernel");
 }
 

@@ -10,7 +10,6 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-
 // A fragment in flight: for the k-major image one ds_read_b128 the compiler tracks; for
 // the k-row image two ds_read_b64_tr_b16 issued from INLINE ASM.  The builtin form makes
 // hipcc put `s_waitcnt vmcnt(0)` in front of every transposed read while an LDS-DMA is

@@ -222,11 +222,10 @@ class VitEngine:
         self.gemm_impl = GEMM_AUTO
         self.reducer = None          # ddp.GradReducer: told when a section's grads are final
         self.profile = None          # list of (name, flops, start_event, end_event) when profiling
-        # backward runs the weight-gradient GEMMs and bias column sums of a block on a second
-        # HIP stream, beside the data-gradient chain: they only consume, and the partial last
-        # wave of a 591-tile dgrad launch (2.3 rounds on 256 CUs) is filled by wgrad tiles
-        self.overlap_wgrad = os.environ.get("VITMI_OVERLAP_WGRAD", "1") != "0"
-        self._side = None
+        # (round 1 ran the weight-gradient GEMMs on a second HIP stream; A/B on one box,
+        # profiles/r02_ab_overlap*: 38.47-38.67 ms/step without it, 38.55-39.26 with it — a
+        # 256x256-tile GEMM workgroup owns its CU's whole register file and 128 KiB of LDS, so
+        # two GEMM kernels only take CUs from each other.  Removed.)
         self.fused_bias_grads = os.environ.get("VITMI_FUSED_BIAS_GRADS", "1") != "0"
 
     def is_current(self) -> bool:
@@ -407,34 +406,7 @@ class VitEngine:
             ops.cast(G, Gb)
         gb_out = None if T == R else Gb
 
-        # Side stream for the consumers-only work (weight gradients, bias sums).  Needs a fresh
-        # Gb buffer per LayerNorm backward (the side stream may still be reading the old one),
-        # so it is used only when Gb is a separate buffer; per-launch profiling serialises.
-        overlap = self.overlap_wgrad and T != R and self.profile is None
         fused_bias = self.fused_bias_grads and T == torch.bfloat16 and self.gemm_impl == GEMM_AUTO
-        main = torch.cuda.current_stream()
-        if overlap and self._side is None:
-            self._side = torch.cuda.Stream(device=dev)
-        side = self._side if overlap else None
-        pending = []                 # (event, block, tensors the side stream may still read)
-
-        def on_side(fn):
-            """Run fn's launches on the side stream, ordered after everything enqueued so far."""
-            if side is None:
-                return fn()
-            ev = torch.cuda.Event()
-            ev.record(main)
-            side.wait_event(ev)
-            with torch.cuda.stream(side):
-                fn()
-
-        def retire(keep):
-            """Join side work older than `keep` blocks: its grads are final, its inputs free."""
-            while len(pending) > keep:
-                ev, blk_done, _refs = pending.pop(0)
-                if ev is not None:
-                    main.wait_event(ev)
-                self._ready(blk_done)
 
         saved_blocks = s["blocks"]
         blocks_list = list(m.blocks)
@@ -454,56 +426,34 @@ class VitEngine:
                 dH_part = torch.empty(((M + 127) // 128, Dh), dtype=torch.float32, device=dev)
             self._gemm(Gb, self._w(mlp.fc2.weight), dH, b_kmajor=False, epilogue=EPI_DGELU, aux=pre,
                        **({"colsum_part": dH_part} if dH_part is not None else {}))
-            Gb_mlp = Gb
-
-            def mlp_wgrads():
-                self._gemm(Gb_mlp, hid, pk.g(mlp.fc2.weight), a_kmajor=False, b_kmajor=False)
-                self._gemm(dH, ln2, pk.g(mlp.fc1.weight), a_kmajor=False, b_kmajor=False)
-                ops.colsum(dH_part if dH_part is not None else dH, pk.g(mlp.fc1.bias))
-            on_side(mlp_wgrads)
+            self._gemm(Gb, hid, pk.g(mlp.fc2.weight), a_kmajor=False, b_kmajor=False)
+            self._gemm(dH, ln2, pk.g(mlp.fc1.weight), a_kmajor=False, b_kmajor=False)
+            ops.colsum(dH_part if dH_part is not None else dH, pk.g(mlp.fc1.bias))
             dln2 = new(M, D, T)
             self._gemm(dH, self._w(mlp.fc1.weight), dln2, b_kmajor=False)
-            if overlap:
-                Gb = new(M, D, T)
-                gb_out = Gb
             ops.layernorm_bwd(dln2, X1, mean2, rstd2, pk.f32(blk.norm2.weight), G, G, gb_out,
                               pk.g(blk.norm2.weight), pk.g(blk.norm2.bias), gsum=pk.g(a.proj.bias),
                               M=M, D=D)
             # attention branch
             dO = new(M, D, T)
             self._gemm(Gb, self._w(a.proj.weight), dO, b_kmajor=False)
-            Gb_attn = Gb
-            on_side(lambda: self._gemm(Gb_attn, O, pk.g(a.proj.weight), a_kmajor=False, b_kmajor=False))
+            self._gemm(Gb, O, pk.g(a.proj.weight), a_kmajor=False, b_kmajor=False)
             dqkv = new(M, 3 * D, T)
             dqkv_part = None
             if fused_bias and a.qkv.bias is not None:
                 dqkv_part = torch.empty((ops.attn_bwd_dbias_rows(B, N), 3 * D), dtype=torch.float32, device=dev)
             ops.attn_bwd(qkv, O, dO, lse, dqkv, B, N, H, hd, a.scale, dbias_part=dqkv_part)
-
-            def qkv_wgrads():
-                self._gemm(dqkv, ln1, pk.g(a.qkv.weight), a_kmajor=False, b_kmajor=False)
-                if a.qkv.bias is not None:
-                    ops.colsum(dqkv_part if dqkv_part is not None else dqkv, pk.g(a.qkv.bias))
-            on_side(qkv_wgrads)
+            self._gemm(dqkv, ln1, pk.g(a.qkv.weight), a_kmajor=False, b_kmajor=False)
+            if a.qkv.bias is not None:
+                ops.colsum(dqkv_part if dqkv_part is not None else dqkv, pk.g(a.qkv.bias))
             dln1 = new(M, D, T)
             self._gemm(dqkv, self._w(a.qkv.weight), dln1, b_kmajor=False)
-            if overlap:
-                Gb = new(M, D, T)
-                gb_out = Gb
             # the gradient this leaves in G flows into the previous block's fc2 output
             prev_fc2_bias = blocks_list[bi - 1].mlp.fc2.bias if bi > 0 else None
             ops.layernorm_bwd(dln1, X, mean1, rstd1, pk.f32(blk.norm1.weight), G, G, gb_out,
                               pk.g(blk.norm1.weight), pk.g(blk.norm1.bias),
                               gsum=pk.g(prev_fc2_bias) if prev_fc2_bias is not None else None, M=M, D=D)
-            ev = None
-            if side is not None:
-                ev = torch.cuda.Event()
-                ev.record(side)
-            # the caching allocator hands a freed block back to the main stream at once: keep
-            # what the side stream reads alive until the main stream has waited for it
-            pending.append((ev, blk, (Gb_mlp, Gb_attn, dH, dqkv, hid, ln2, ln1, O, dH_part, dqkv_part)))
-            retire(1)
-        retire(0)
+            self._ready(blk)
 
         # ---- embeddings ----
         conv = m.patch_embed.proj
