@@ -406,10 +406,11 @@ FAST_SHAPES = [(256, 256, 64), (512, 768, 768), (768, 512, 1024), (1024, 256, 12
                (512, 256, 6464), (256, 128, 64), (512, 384, 320)]
 
 
-@pytest.fixture(params=["t1p0", "t1p1", "t1p2", "t1p3", "t2"])
+@pytest.fixture(params=["t1p0", "t1p1", "t1p2", "t1p3", "t2", "t1p1-oneshot", "t1p2-oneshot"])
 def pipe(request, lib):
     """Run a test once per variant of the fast GEMM — 256x256 tiles with the simple /
-    4-slab-ring / 64-deep-stage / 3-slab-ring (residual epilogue only) main loops, and 256x128 tiles with two workgroups per CU —
+    4-slab-ring / 64-deep-stage / 3-slab-ring (residual epilogue only) main loops, persistent (one
+    workgroup per CU walking tiles, default) or one tile per workgroup, and 256x128 tiles with two workgroups per CU —
     through the diagnostic hooks the library exports."""
     import ctypes
     from vit_torch_amd import _lib as L
@@ -418,10 +419,12 @@ def pipe(request, lib):
         raw.vitmi_debug_gemm_tile(2)
     else:
         raw.vitmi_debug_gemm_tile(1)
-        raw.vitmi_debug_gemm_pipe(int(request.param[-1]))
+        raw.vitmi_debug_gemm_pipe(int(request.param[3]))
+        raw.vitmi_debug_gemm_persist(0 if request.param.endswith("oneshot") else 1)   # grid = tiles (round-1 form)
     yield request.param
     raw.vitmi_debug_gemm_pipe(-1)
     raw.vitmi_debug_gemm_tile(-1)
+    raw.vitmi_debug_gemm_persist(1)
 
 
 @pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
@@ -669,3 +672,56 @@ def test_gemm_residual_fold_through_lds(ops, lib, M, N, K):
         assert torch.equal(Xi.cpu(), outs[1])
     finally:
         raw.vitmi_debug_gemm_rfold(-1)
+
+
+@pytest.mark.parametrize("layout,epi", [("nt", "store"), ("nt", "gelu"), ("nt", "res"), ("nn", "dgelu"), ("nn", "store")])
+def test_gemm_persistent_walk_covers_many_tiles_per_workgroup(ops, lib, layout, epi):
+    """More tiles than CUs (3 x 256 + a ragged remainder): every persistent workgroup walks several
+    tiles, prefetching the next tile's stages before its epilogue.  Must equal the one-tile-per-
+    workgroup launch bit for bit (same arithmetic, same order) and the torch reference."""
+    import ctypes
+    from vit_torch_amd import _lib as L
+    from vit_torch_amd._lib import EPI_BIAS_GELU, EPI_DGELU, EPI_RESIDUAL, EPI_STORE, GEMM_FAST
+    raw = ctypes.CDLL(str(L.LIB_PATH))
+    M, N, K = 256 * 67, 256 * 13, 768                    # 871 tiles = 3.4 rounds on 256 CUs
+    bt = torch.bfloat16
+    akm, bkm = (True, True) if layout == "nt" else (True, False)
+    g = torch.Generator("cpu").manual_seed(77)
+    a = bf16_round(torch.randn(M, K, generator=g))
+    b = bf16_round(torch.randn(N, K, generator=g) * 0.05)
+    A = dev(a, bt)
+    B = dev(b if bkm else b.t().contiguous(), bt)
+    bias = dev(torch.randn(N, generator=g))
+    Rres = dev(torch.randn(M, N, generator=g)) if epi == "res" else None
+    acc = a @ b.t()
+    outs = []
+    for persist in (1, 0):
+        raw.vitmi_debug_gemm_persist(persist)
+        try:
+            if epi == "store":
+                C = torch.full((M, N), float("nan"), device="cuda").to(bt)
+                ops.gemm(A, B, C, a_kmajor=akm, b_kmajor=bkm, bias=bias if layout == "nt" else None, impl=GEMM_FAST)
+                want = acc + (bias.cpu() if layout == "nt" else 0)
+                res = (C,)
+            elif epi == "gelu":
+                C, P = (torch.full((M, N), float("nan"), device="cuda").to(bt) for _ in range(2))
+                ops.gemm(A, B, C, epilogue=EPI_BIAS_GELU, bias=bias, C2=P, impl=GEMM_FAST)
+                want = F.gelu(bf16_round(acc + bias.cpu()))
+                res = (C, P)
+            elif epi == "res":
+                C = torch.full((M, N), float("nan"), device="cuda")
+                ops.gemm(A, B, C, epilogue=EPI_RESIDUAL, bias=bias, R=Rres, impl=GEMM_FAST)
+                want = Rres.cpu() + acc + bias.cpu()
+                res = (C,)
+            else:
+                aux = dev(bf16_round(torch.randn(M, N, generator=torch.Generator("cpu").manual_seed(79))), bt)
+                C = torch.full((M, N), float("nan"), device="cuda").to(bt)
+                ops.gemm(A, B, C, a_kmajor=akm, b_kmajor=bkm, epilogue=EPI_DGELU, aux=aux, impl=GEMM_FAST)
+                want = acc * gelu_grad(aux.float().cpu())
+                res = (C,)
+        finally:
+            raw.vitmi_debug_gemm_persist(1)
+        assert_close(f"{layout}/{epi} persist={persist}", res[0], want, 1e-4 if res[0].dtype == torch.float32 else TOL[bt])
+        outs.append([t.float().cpu() for t in res])
+    for x, y in zip(outs[0], outs[1]):
+        assert torch.equal(x, y), "persistent and one-tile-per-workgroup launches must agree bit for bit"

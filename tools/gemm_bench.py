@@ -55,11 +55,14 @@ if __name__ == "__main__":
     raw = ctypes.CDLL(str(_lib.LIB_PATH))
     specs = [a for a in sys.argv[1:] if not a.startswith("pipe=")]
     specs = [a for a in specs if not a.startswith("tile=")]
+    persists = [int(a[8:]) for a in specs if a.startswith("persist=")] or [1]
+    specs = [a for a in specs if not a.startswith("persist=")]
     pipes = [int(a[5:]) for a in sys.argv[1:] if a.startswith("pipe=")] or [-1]
     tiles = [int(a[5:]) for a in sys.argv[1:] if a.startswith("tile=")] or [-1]
-    for tm, pm in [(t, p) for t in tiles for p in pipes]:
+    for tm, pm, ps in [(t, p, q) for t in tiles for p in pipes for q in persists]:
         raw.vitmi_debug_gemm_tile(tm)
         raw.vitmi_debug_gemm_pipe(pm)
-        print(f"--- tile {tm} pipe {pm}")
+        raw.vitmi_debug_gemm_persist(ps)
+        print(f"--- tile {tm} pipe {pm} persistent {ps}")
         for s in (specs or DEFAULT):
             run(s)

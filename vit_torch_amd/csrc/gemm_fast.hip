@@ -275,49 +275,144 @@ __device__ __forceinline__ bool g_rfold_enabled(const GemmArgs& g) {
   return g.rfold != 0 && !g.e.gamma && !g.e.rowscale && !g.e.C2 && !g.e.r_bf16;
 }
 
+// s_waitcnt vmcnt(N) with a compile-time N (counted waits of the persistent prologue)
+template <int N> __device__ __forceinline__ void wait_vm_c() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// the wave's 16-row x 64-column fp32 transposition strip of the epilogue: 4 KiB, 16-B chunk c of
+// row r at chunk c ^ r (conflict-free for the accumulator-shaped ds_write_b128 and for the
+// row-shaped ds_read_b128 of both output widths)
+__device__ __forceinline__ float* strip_at(float* tr, int row, int col) {
+  return tr + row * 64 + ((((col >> 2) ^ row) & 15) << 2);
+}
+
+// PERSISTENT tile walk (every launch but split-K): the grid is min(tiles, CUs) workgroups, one per
+// CU (a workgroup takes the CU's whole register file and >= 128 KiB of LDS), and each walks the
+// tiles slot, slot + G/8, ... of its XCD's contiguous run (the same tile -> XCD order as before).
+// When the main loop of a tile ends the operand stages are free, so the LDS-DMA of the NEXT
+// tile's first stages is issued BEFORE the epilogue: the ~5 k cycles a tile spent between its
+// first DMA and its first MFMA (launch, plan set-up, HBM / L2 round trip) now run under the
+// epilogue's stores.  The transposition strips therefore live in the LDS above the stages
+// (bytes 128 Ki .. 160 Ki; PIPE 3: the second residual strip of each wave).
+// vmcnt of the first wait of a prefetched tile: the epilogue's VMEM operations are YOUNGER than the
+// prefetch, so they are added to the count of younger DMAs; only the stores to C are counted
+// (a lower bound: fewer outstanding operations than allowed is always safe).
 template <bool A_KM, bool B_KM, int MODE, typename TC, bool SPLITK = false, int PIPE = 0>
 __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int tiles_n, int nwg,
                                                              int ntiles, int ksps, float* ws, int tile0) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (A tile | B tile)
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // stages | strips
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
+  constexpr bool PERSIST = !SPLITK;
+  constexpr int W = sizeof(TC) == 2 ? 8 : 4;       // columns per lane in the row pass
+  constexpr int LPR = 64 / W;                      // lanes per 64-column row
+  constexpr int RPI = 64 / LPR;                    // rows per wave instruction
+  constexpr int NJ = 16 / RPI;                     // row groups per strip
+  constexpr int E_MIN = 8 * NJ;                    // stores to C every epilogue issues
 
-  // XCD-aware, bijective remap (guide §5: blocks b and b+8 share an XCD)
+  // XCD-aware, bijective tile map (guide §5: blocks b and b+8 share an XCD): XCD x owns the
+  // contiguous run [x_start, x_start + x_len) of the nwg tiles, n fastest inside it
   const int bid = blockIdx.x;
   const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  // consecutive wg share the split (k range) and walk the tiles: operand panels stay in L2
-  const int split = SPLITK ? wg / ntiles : 0;
-  const int tile = tile0 + (SPLITK ? wg % ntiles : wg);   // tile0: first tile of a partial launch
-  const int64_t m0 = (int64_t)(tile / tiles_n) * BM;
-  const int64_t n0 = (int64_t)(tile % tiles_n) * BN;
+  const int x_start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int x_len = q + (xcd < r ? 1 : 0);
+  const int slot = bid >> 3;
+  const int gx = PERSIST ? (((int)gridDim.x - xcd + 7) >> 3) : 1;   // workgroups of this XCD
+  // split-K: the grid is (tiles x splits), one (tile, split) per workgroup
+  const int wg0 = x_start + slot;
+  const int split = SPLITK ? wg0 / ntiles : 0;
 
   const bf16* A = reinterpret_cast<const bf16*>(g.A);
   const bf16* B = reinterpret_cast<const bf16*>(g.B);
-
-  f32x4 acc[4][8];   // [ni][mi]: D^T blocks, lane holds row m = l&15, cols n = 4*(l>>4)+r
-#pragma unroll
-  for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi) { acc[ni][mi][0] = 0.f; acc[ni][mi][1] = 0.f; acc[ni][mi][2] = 0.f; acc[ni][mi][3] = 0.f; }
-
   const int nt_all = (int)(g.K / BK);
   const int kt0 = SPLITK ? split * ksps : 0;
   const int nt = SPLITK ? min(ksps, nt_all - kt0) : nt_all;
+  const int64_t kb0 = (int64_t)kt0 * BK;
   // residual fold (see ResFold): compiled into the PIPE 3 loop of the fp32-stream residual
   // epilogue, taken when nothing scales the branch and the contraction has the 19 slabs the
   // eight strips need
   constexpr bool RFOLD_T = MODE == VITMI_EPI_RESIDUAL && sizeof(TC) == 4 && !SPLITK && PIPE == 3;
   const bool rfold = RFOLD_T && g_rfold_enabled(g) && nt >= 10;
   // diagnostic build of the timeline (armed by tools/gemm_phases.py only): entry,
-  // epilogue start and end of the first 64 blocks, wave 0
+  // epilogue start and end of the first tile of the first blocks, wave 0
   const bool dbg_tl = g.dbg != nullptr && (int)blockIdx.x < g.dbg_blocks && wave == 0;
+  const bool dbg = g.dbg != nullptr && blockIdx.x == 0;   // wave-uniform
   unsigned long long tl0 = 0;
   if (dbg_tl) tl0 = stamp();
+
+  // ---- per-PIPE staging plans and fragment offsets (lane parts are tile independent)
+  constexpr bool RINGP = PIPE == 1 || PIPE == 3;
+  constexpr int RING = PIPE == 3 ? 3 : 4;          // slabs resident; RING - 1 are prefetched ahead
+  constexpr int AHEAD = RING - 1;
+  const int ns = 2 * nt;                           // 32-deep slabs
+  const int grp = wm;                              // 0: leads, 1: one barrier behind
+  SlabPlan<A_KM> sa;
+  SlabPlan<B_KM> sb;
+  StagePlan<A_KM> ta;
+  StagePlan<B_KM> tb;
+  ResFold rf;
+  uint32_t fa[8], fb[4];
+  if constexpr (RINGP) {
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) fa[mi] = frag_off<A_KM>(wm * 8 + mi, lane);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) fb[ni] = frag_off<B_KM>(wn * 4 + ni, lane) + SLAB_BYTES;
+  } else if constexpr (PIPE == 2) {
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) fa[mi] = frag_off64<A_KM>(wm * 8 + mi, lane);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) fb[ni] = frag_off64<B_KM>(wn * 4 + ni, lane);
+  }
+  char* rstrip = smem + RF_BASE + wave * 2 * RF_STRIP;   // PIPE 3: this wave's two residual strip buffers
+  // epilogue strip: above the stages (the stages may already be receiving the next tile)
+  float* tr = reinterpret_cast<float*>(PIPE == 3 ? rstrip + RF_STRIP : smem + (SPLITK ? 0 : 2 * STAGE_BYTES) + wave * 4096);
+
+  // plans of a tile + the DMAs that precede its main loop
+  auto start_tile = [&](int64_t m0, int64_t n0) {
+    if constexpr (RINGP) {
+      sa.init(A, g.lda, m0, kb0, wave, lane);
+      sb.init(B, g.ldb, n0, kb0, wave, lane);
+      if constexpr (RFOLD_T) { if (rfold) rf.init(reinterpret_cast<const float*>(g.e.R), g.e.ldr, m0, n0, wm, wn, lane); }
+#pragma unroll
+      for (int a = 0; a < AHEAD; ++a)
+        if (a < ns) {
+          char* st = smem + a * RING_STAGE;
+          sa.issue(st, a, wave);
+          sb.issue(st + SLAB_BYTES, a, wave);
+        }
+      if constexpr (RFOLD_T) { if (rfold) rf.issue(rstrip, 0); }     // strip 0 rides behind the prologue slabs
+    } else if constexpr (PIPE == 2) {
+      ta.init(A, g.lda, m0, kb0, wave, lane);
+      tb.init(B, g.ldb, n0, kb0, wave, lane);
+      ta.issue(smem, 0, wave);
+      tb.issue(smem + TILE_BYTES, 0, wave);
+      if (nt > 1) {
+        ta.issue(smem + STAGE_BYTES, 1, wave);
+        tb.issue(smem + STAGE_BYTES + TILE_BYTES, 1, wave);
+      }
+    }
+  };
+
+  int idx = slot;                                  // position inside the XCD's run (PERSIST)
+  int tile = tile0 + (SPLITK ? wg0 % ntiles : x_start + idx);
+  if (PERSIST && idx >= x_len) return;
+  int64_t m0 = (int64_t)(tile / tiles_n) * BM, n0 = (int64_t)(tile % tiles_n) * BN;
+  start_tile(m0, n0);
+  bool prefetched = false;                         // the tile's prologue DMAs were issued before an epilogue
+
+#pragma unroll 1
+  for (;;) {
+  f32x4 acc[4][8];   // [ni][mi]: D^T blocks, lane holds row m = l&15, cols n = 4*(l>>4)+r
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) { acc[ni][mi][0] = 0.f; acc[ni][mi][1] = 0.f; acc[ni][mi][2] = 0.f; acc[ni][mi][3] = 0.f; }
+
   if constexpr (PIPE == 0) {
-  stage_tile<A_KM>(smem, A, g.lda, m0, (int64_t)kt0 * BK, wave, lane);
-  stage_tile<B_KM>(smem + TILE_BYTES, B, g.ldb, n0, (int64_t)kt0 * BK, wave, lane);
+  stage_tile<A_KM>(smem, A, g.lda, m0, kb0, wave, lane);
+  stage_tile<B_KM>(smem + TILE_BYTES, B, g.ldb, n0, kb0, wave, lane);
   __syncthreads();
 
   for (int t = 0; t < nt; ++t) {
@@ -345,48 +440,34 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
     __syncthreads();   // next stage landed (vmcnt(0)) and everyone is done reading `cur`
   }
 
-  } else if constexpr (PIPE == 1 || PIPE == 3) {
-    constexpr int RING = PIPE == 3 ? 3 : 4;        // slabs resident; RING - 1 are prefetched ahead
-    constexpr int AHEAD = RING - 1;
-    const int ns = 2 * nt;                         // 32-deep slabs
-    const int64_t kb0 = (int64_t)kt0 * BK;
-    const int grp = wm;                            // 0: leads, 1: one barrier behind
-    SlabPlan<A_KM> pa;
-    SlabPlan<B_KM> pb_;
-    pa.init(A, g.lda, m0, kb0, wave, lane);
-    pb_.init(B, g.ldb, n0, kb0, wave, lane);
-    uint32_t fa[8], fb[4];
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi) fa[mi] = frag_off<A_KM>(wm * 8 + mi, lane);
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) fb[ni] = frag_off<B_KM>(wn * 4 + ni, lane) + SLAB_BYTES;
+  } else if constexpr (RINGP) {
     int stage_i = 0;                               // j % RING without a division
     auto stage_of = [&](int ahead) { int x = stage_i + ahead; return x >= RING ? x - RING : x; };
-    auto issue = [&](int j, int st_idx) {
-      char* st = smem + st_idx * RING_STAGE;
-      pa.issue(st, j, wave);
-      pb_.issue(st + SLAB_BYTES, j, wave);
-    };
-    ResFold rf;
-    if constexpr (RFOLD_T) { if (rfold) rf.init(reinterpret_cast<const float*>(g.e.R), g.e.ldr, m0, n0, wm, wn, lane); }
-    char* rstrip = smem + RF_BASE + wave * 2 * RF_STRIP;   // this wave's two strip buffers
-#pragma unroll
-    for (int a = 0; a < AHEAD; ++a)
-      if (a < ns) issue(a, a);
-    if constexpr (RFOLD_T) { if (rfold) rf.issue(rstrip, 0); }       // strip 0 rides behind the prologue slabs
-    {   // slab 0 has landed: everything issued after it may still fly
-      const int younger = min(ns, AHEAD) - 1;
-      wait_vm(4 * younger + ((RFOLD_T && rfold) ? 4 : 0));
+    {   // slab 0 has landed: everything issued after it may still fly (later slabs, the residual
+        // strip, and, behind a prefetch, the previous tile's epilogue)
+      const int younger = 4 * (min(ns, AHEAD) - 1) + ((RFOLD_T && rfold) ? 4 : 0);
+      if (prefetched) {
+        if (younger >= 12) wait_vm_c<12 + E_MIN>();
+        else if (younger >= 8) wait_vm_c<8 + E_MIN>();
+        else if (younger >= 4) wait_vm_c<4 + E_MIN>();
+        else wait_vm_c<E_MIN>();
+      } else {
+        if (younger >= 12) wait_vm_c<12>();
+        else wait_vm(younger);
+      }
     }
     raw_barrier();                                 // b0
     if (grp == 1) raw_barrier();                   // stagger
-    const bool dbg = g.dbg != nullptr && blockIdx.x == 0;   // wave-uniform
     unsigned long long tR = 0, tWR = 0, tM = 0, tWM = 0, t0 = 0, t1 = 0;
 #pragma unroll 1
     for (int j = 0; j < ns; ++j) {
       if (dbg) t0 = stamp();
       // ---- R(j)
-      if (j + AHEAD < ns) issue(j + AHEAD, stage_of(AHEAD));
+      if (j + AHEAD < ns) {
+        char* st = smem + stage_of(AHEAD) * RING_STAGE;
+        sa.issue(st, j + AHEAD, wave);
+        sb.issue(st + SLAB_BYTES, j + AHEAD, wave);
+      }
       const char* As = smem + stage_i * RING_STAGE;
       Frag<B_KM> fbv[4];
       Frag<A_KM> fav[8];
@@ -453,7 +534,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
       if (dbg) { t0 = stamp(); tWM += t0 - t1; }
       stage_i = stage_i == RING - 1 ? 0 : stage_i + 1;
     }
-    if (dbg && lane == 0) {
+    if (dbg && lane == 0 && !prefetched) {
       g.dbg[wave * 4 + 0] = tR; g.dbg[wave * 4 + 1] = tWR;
       g.dbg[wave * 4 + 2] = tM; g.dbg[wave * 4 + 3] = tWM;
       g.dbg[32 + wave] = ns;
@@ -462,35 +543,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
     // PIPE == 2: two 64-deep stages (full-line LDS-DMA), the same two wave groups one
     // barrier apart; stage t+1 is issued at R(2t) into the buffer stage t-1 has just
     // vacated and waited for (vmcnt(0)) at the end of phase 2t+1.
-    const int ns = 2 * nt;
-    const int64_t kb0 = (int64_t)kt0 * BK;
-    const int grp = wm;
-    StagePlan<A_KM> pa;
-    StagePlan<B_KM> pb_;
-    pa.init(A, g.lda, m0, kb0, wave, lane);
-    pb_.init(B, g.ldb, n0, kb0, wave, lane);
-    uint32_t fa[8], fb[4];
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi) fa[mi] = frag_off64<A_KM>(wm * 8 + mi, lane);
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) fb[ni] = frag_off64<B_KM>(wn * 4 + ni, lane);
-    auto issue = [&](int t) {
-      char* st = smem + (t & 1) * STAGE_BYTES;
-      pa.issue(st, t, wave);
-      pb_.issue(st + TILE_BYTES, t, wave);
-    };
-    issue(0);
-    if (nt > 1) issue(1);
-    wait_vm(nt > 1 ? 8 : 0);
+    if (prefetched) { if (nt > 1) wait_vm_c<8 + E_MIN>(); else wait_vm_c<E_MIN>(); }
+    else wait_vm(nt > 1 ? 8 : 0);
     raw_barrier();
     if (grp == 1) raw_barrier();
-    const bool dbg = g.dbg != nullptr && blockIdx.x == 0;
     unsigned long long tR = 0, tWR = 0, tM = 0, tWM = 0, t0 = 0, t1 = 0;
 #pragma unroll 1
     for (int j = 0; j < ns; ++j) {
       if (dbg) t0 = stamp();
       const int t = j >> 1, kh = j & 1;
-      if (kh == 0 && t >= 1 && t + 1 < nt) issue(t + 1);
+      if (kh == 0 && t >= 1 && t + 1 < nt) {
+        char* st = smem + ((t + 1) & 1) * STAGE_BYTES;
+        ta.issue(st, t + 1, wave);
+        tb.issue(st + TILE_BYTES, t + 1, wave);
+      }
       const char* At = smem + (t & 1) * STAGE_BYTES;
       const char* Bt = At + TILE_BYTES;
       Frag<B_KM> fbv[4];
@@ -522,7 +588,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
       if (!(grp == 1 && j == ns - 1)) raw_barrier();
       if (dbg) { t0 = stamp(); tWM += t0 - t1; }
     }
-    if (dbg && lane == 0) {
+    if (dbg && lane == 0 && !prefetched) {
       g.dbg[wave * 4 + 0] = tR; g.dbg[wave * 4 + 1] = tWR;
       g.dbg[wave * 4 + 2] = tM; g.dbg[wave * 4 + 3] = tWM;
       g.dbg[32 + wave] = ns;
@@ -532,17 +598,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
   // ---- epilogue.  The accumulators hold 16x16 blocks with 4 columns per lane; stored
   // as they are, one wave instruction touches 16 rows x 32..64 B (16 partial lines) and
   // the tile's store tail is issue-bound (~8 B/clk/CU measured).  Instead each wave
-  // transposes one 16-row x 64-column strip at a time through a PRIVATE 4.25-KiB LDS
-  // strip (the stage buffers are free after the last barrier; same-wave DS ops execute
-  // in order, so no barrier is needed) and then reads, post-processes and stores whole
-  // rows: every global access of the epilogue (C, C2, R, AUX) is 16 B per lane and
-  // covers full 128-B lines.
+  // transposes one 16-row x 64-column strip at a time through a PRIVATE 4-KiB LDS strip
+  // (same-wave DS ops execute in order, so no barrier is needed) and then reads,
+  // post-processes and stores whole rows: every global access of the epilogue (C, C2, R,
+  // AUX) is 16 B per lane and covers full 128-B lines.
   unsigned long long tl1 = 0;
-  if (dbg_tl) tl1 = stamp();
-  constexpr int W = sizeof(TC) == 2 ? 8 : 4;       // columns per lane in the row pass
-  constexpr int LPR = 64 / W;                      // lanes per 64-column row
-  constexpr int RPI = 64 / LPR;                    // rows per wave instruction
-  float* tr = reinterpret_cast<float*>(smem + wave * TR_BYTES);
+  if (dbg_tl && !prefetched) tl1 = stamp();
   const int lr = lane & 15, lg = lane >> 4;
   const int rr = lane / LPR, rc = (lane % LPR) * W;
   float bias_r[W], gamma_r[W];
@@ -552,7 +613,23 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
     if (g.e.bias) loadv<float, W>(g.e.bias + n0 + wn * 64 + rc, bias_r);
     if (MODE == VITMI_EPI_RESIDUAL && g.e.gamma) loadv<float, W>(g.e.gamma + n0 + wn * 64 + rc, gamma_r);
   }
-  constexpr int NJ = 16 / RPI;                     // row groups per strip
+  // ---- the next tile of this workgroup: its first stages start to fill now
+  bool has_next = false;
+  int64_t m0n = 0, n0n = 0;
+  if constexpr (PERSIST && PIPE != 0) {
+    const int nidx = idx + gx;
+    has_next = nidx < x_len;
+    if (has_next) {
+      // bias / LayerScale first and waited for with a wait the compiler SEES: while an LDS-DMA is
+      // in flight hipcc answers the first use of any ordinary load with vmcnt(0), which would
+      // put the whole prefetch in front of the epilogue
+      __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): nothing but these two small loads is outstanding
+      const int tn = x_start + nidx;
+      m0n = (int64_t)(tn / tiles_n) * BM;
+      n0n = (int64_t)(tn % tiles_n) * BN;
+      start_tile(m0n, n0n);
+    }
+  }
   // (residual fold: R is already inside the accumulators; x = 0, gamma = 1 -> v = acc + b)
   const bool side = !SPLITK && epi_has_side<MODE, TC>(g.e) && !rfold;
   const int64_t ncol = n0 + wn * 64 + rc;
@@ -577,14 +654,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
     }
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
-      *reinterpret_cast<f32x4*>(tr + lr * TRS + ni * 16 + lg * 4) = acc[ni][mi];
+      *reinterpret_cast<f32x4*>(strip_at(tr, lr, ni * 16 + lg * 4)) = acc[ni][mi];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int row = j * RPI + rr;
       float v[W];
 #pragma unroll
       for (int qq = 0; qq < W / 4; ++qq) {
-        const f32x4 t4 = *reinterpret_cast<const f32x4*>(tr + row * TRS + rc + 4 * qq);
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(strip_at(tr, row, rc + 4 * qq));
         v[4 * qq] = t4[0]; v[4 * qq + 1] = t4[1]; v[4 * qq + 2] = t4[2]; v[4 * qq + 3] = t4[3];
       }
       if constexpr (SPLITK)
@@ -610,7 +687,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
       if (rr == 0) storev<float, W>(g.e.colsum_part + ((m0 >> 7) + wm) * g.N + ncol, cs);
     }
   }
-  if (dbg_tl) {
+  if (dbg_tl && !prefetched) {
     wait_vm(0);                                    // stores retired = the wave could end here
     const unsigned long long tl2 = stamp();
     if (lane == 0) {
@@ -620,6 +697,23 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
       asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt) :: "memory");
       g.dbg[64 + blockIdx.x * 4 + 3] = rt;
     }
+  }
+  // ---- next tile
+  if constexpr (!PERSIST) break;
+  else if constexpr (PIPE == 0) {
+    idx += gx;
+    if (idx >= x_len) break;
+    tile = x_start + idx;
+    m0 = (int64_t)(tile / tiles_n) * BM;
+    n0 = (int64_t)(tile % tiles_n) * BN;
+    __syncthreads();                               // the strips of PIPE 0 sit above the stages too; stages reused at once
+  } else {
+    if (!has_next) break;
+    idx += gx;
+    m0 = m0n;
+    n0 = n0n;
+    prefetched = true;
+  }
   }
 }
 
@@ -755,9 +849,21 @@ int launch(const GemmArgs& g, hipStream_t stream) {
   return launch_p<A_KM, B_KM, MODE, TC, 2>(g, stream);
 }
 
+// split-K: two stages (strips alias them after the loop); persistent launches: stages + 32 KiB of
+// strips above them = the CU's 160 KiB (PIPE 3: ring of three + residual strips, the same size)
 template <int MODE, typename TC, bool SPLITK, int PIPE>
 constexpr int lds_bytes() {
-  return (MODE == VITMI_EPI_RESIDUAL && sizeof(TC) == 4 && !SPLITK && PIPE == 3) ? RF_LDS : 2 * STAGE_BYTES;
+  return SPLITK ? 2 * STAGE_BYTES : RF_LDS;
+}
+static int g_persist = 1;
+// diagnostic / test hook: 0 = one tile per workgroup (grid = tiles), 1 = persistent grid (one workgroup per CU)
+extern "C" void vitmi_debug_gemm_persist(int on) { g_persist = on; }
+static int persistent_grid(int nwg) {
+  if (!g_persist) return nwg;
+  int cus = vitmi_cu_count();
+  cus -= cus % 8;                                  // whole XCD rows: every XCD gets the same number of workgroups
+  if (cus < 8) cus = 8;
+  return nwg < cus ? nwg : cus;
 }
 
 template <bool A_KM, bool B_KM, int MODE, typename TC, int PIPE>
@@ -797,7 +903,7 @@ int launch_p(const GemmArgs& g_in, hipStream_t stream) {
       if (int rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(kmain), LDSM, "gemm_fast")) return rc;
       if (int rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(ktail), 2 * STAGE_BYTES, "gemm_fast(tail)")) return rc;
       float* ws = reinterpret_cast<float*>(g.ws);
-      hipLaunchKernelGGL(kmain, dim3(full), dim3(NTHREADS), LDSM, stream, g, tiles_n, full, full, 0, (float*)nullptr, 0);
+      hipLaunchKernelGGL(kmain, dim3(persistent_grid(full)), dim3(NTHREADS), LDSM, stream, g, tiles_n, full, full, 0, (float*)nullptr, 0);
       int rc = vitmi_check_launch("gemm_fast_kernel(full rounds)");
       if (rc) return rc;
       hipLaunchKernelGGL(ktail, dim3(rem * splits), dim3(NTHREADS), 2 * STAGE_BYTES, stream, g, tiles_n, rem * splits, rem, ksps, ws, full);
@@ -809,7 +915,7 @@ int launch_p(const GemmArgs& g_in, hipStream_t stream) {
   auto kern = gemm_fast_kernel<A_KM, B_KM, MODE, TC, false, PIPE>;
   constexpr int LDSK = lds_bytes<MODE, TC, false, PIPE>();
   if (int rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(kern), LDSK, "gemm_fast")) return rc;
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(NTHREADS), LDSK, stream, g, tiles_n, nwg, nwg, 0, (float*)nullptr, 0);
+  hipLaunchKernelGGL(kern, dim3(persistent_grid(nwg)), dim3(NTHREADS), LDSK, stream, g, tiles_n, nwg, nwg, 0, (float*)nullptr, 0);
   return vitmi_check_launch("gemm_fast_kernel");
 }
 
