@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VITMI_VERSION 101
+#define VITMI_VERSION 102
 
 enum { VITMI_F32 = 0, VITMI_BF16 = 1 };
 
@@ -258,9 +258,12 @@ int vitmi_scale_cast(const void* x, int x_dtype, int64_t ldx, const float* scale
 /* im2col for Conv2d(C, D, kernel=p, stride=p) (models/swin.py:434,445):
  * x[B,C,H,W] fp32 with element strides (sb,sc,sh,sw) — NCHW or channels_last —
  * -> rows [B*(cls_rows + (H/p)*(W/p)), C*p*p], k = c*p*p + i*p + j.  With
- * cls_rows=1 row 0 of every image is zero (placeholder for the CLS token). */
+ * cls_rows=1 row 0 of every image is zero (placeholder for the CLS token).
+ * out_ld (elements, % 4 == 0, 0 -> C*p*p): row pitch of `out`; columns [C*p*p, out_ld) are
+ * written as zeros, so a contraction that is not a multiple of the GEMM's 32-deep step (Swin's
+ * 4x4x3 = 48) can be padded to one that is (64) and take the tile kernel. */
 int vitmi_patchify(const float* x, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
-                   void* out, int out_dtype,
+                   void* out, int out_dtype, int64_t out_ld,
                    int64_t B, int64_t C, int64_t H, int64_t W, int64_t p,
                    int cls_rows, void* stream);
 

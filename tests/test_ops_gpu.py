@@ -345,6 +345,12 @@ def test_patchify(ops, B, C, H, p, cls, channels_last):
     outb = torch.empty(out.shape, device="cuda", dtype=torch.bfloat16)
     ops.patchify(xd, outb, p, cls)
     assert torch.equal(outb.cpu(), want.reshape(out.shape).to(torch.bfloat16))
+    # rows at a padded stride: the columns past C*p*p are written as zeros (Swin's 48 -> 64)
+    ld = (out.shape[1] + 31) // 32 * 32 + 32
+    outp = torch.full((out.shape[0], ld), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ops.patchify(xd, outp, p, cls)
+    assert torch.equal(outp[:, :out.shape[1]].cpu(), want.reshape(out.shape).to(torch.bfloat16))
+    assert torch.count_nonzero(outp[:, out.shape[1]:]).item() == 0
 
 
 def test_colsum_narrow_strided_rows(ops):

@@ -83,7 +83,7 @@ SIGNATURES = {
     "vitmi_token_mean": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_vp]),
     "vitmi_cast": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, c_i64, c_vp]),
     "vitmi_scale_cast": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, c_vp, c_i64, c_vp, C.c_int, c_i64, c_i64, c_i64, c_vp]),
-    "vitmi_patchify": (C.c_int, [c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, C.c_int, c_i64, c_i64,
+    "vitmi_patchify": (C.c_int, [c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, C.c_int, c_i64, c_i64, c_i64,
                                  c_i64, c_i64, c_i64, C.c_int, c_vp]),
     "vitmi_colsum_workspace": (c_sz, [c_i64, c_i64]),
     "vitmi_colsum": (C.c_int, [c_vp, C.c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_sz, c_vp]),

@@ -47,12 +47,12 @@ __global__ void scale_cast_kernel(const TS* __restrict__ x, int64_t ldx, const f
 // along W, so 4 consecutive j are contiguous in NCHW when p % 4 == 0)
 template <typename TD>
 __global__ void patchify_kernel(const float* __restrict__ x, int64_t sb, int64_t sc, int64_t sh,
-                                int64_t sw, TD* __restrict__ out, int64_t B, int C, int H, int W,
+                                int64_t sw, TD* __restrict__ out, int64_t out_ld, int64_t B, int C, int H, int W,
                                 int p, int cls_rows) {
   const int gh = H / p, gw = W / p;
   const int ntok = cls_rows + gh * gw;
   const int Kp = C * p * p;
-  const int kq = Kp / 4;
+  const int kq = (int)(out_ld / 4);                // columns [Kp, out_ld) are written as zeros (K padding)
   const int64_t total = B * ntok * (int64_t)kq;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
@@ -61,7 +61,7 @@ __global__ void patchify_kernel(const float* __restrict__ x, int64_t sb, int64_t
     const int t = (int)(row % ntok);
     const int64_t b = row / ntok;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (t >= cls_rows) {
+    if (t >= cls_rows && k4 * 4 < Kp) {
       const int pt = t - cls_rows;
       const int py = pt / gw, px = pt % gw;
       const int k = k4 * 4;
@@ -71,7 +71,7 @@ __global__ void patchify_kernel(const float* __restrict__ x, int64_t sb, int64_t
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = src[e * sw];
     }
-    store4<TD>(out + row * Kp + k4 * 4, v);
+    store4<TD>(out + row * out_ld + k4 * 4, v);
   }
 }
 
@@ -391,21 +391,23 @@ extern "C" int vitmi_scale_cast(const void* x, int x_dtype, int64_t ldx, const f
 }
 
 extern "C" int vitmi_patchify(const float* x, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
-                              void* out, int out_dtype, int64_t B, int64_t C, int64_t H, int64_t W,
+                              void* out, int out_dtype, int64_t out_ld, int64_t B, int64_t C, int64_t H, int64_t W,
                               int64_t p, int cls_rows, void* stream_) {
   VITMI_REQUIRE(x && out && B > 0 && C > 0 && H > 0 && W > 0 && p > 0, VITMI_E_BADARG, "patchify: null pointer or empty shape");
   VITMI_REQUIRE(H % p == 0 && W % p == 0, VITMI_E_SHAPE, "patchify: image %lldx%lld not divisible by patch %lld", (long long)H, (long long)W, (long long)p);
   VITMI_REQUIRE(p % 4 == 0, VITMI_E_SHAPE, "patchify: patch size must be a multiple of 4");
   VITMI_REQUIRE(cls_rows == 0 || cls_rows == 1, VITMI_E_BADARG, "patchify: cls_rows must be 0 or 1");
+  if (out_ld <= 0) out_ld = C * p * p;
+  VITMI_REQUIRE(out_ld >= C * p * p && out_ld % 4 == 0, VITMI_E_BADARG, "patchify: out_ld must be >= C*p*p and a multiple of 4");
   VITMI_REQUIRE(is_aligned(out, 4 * dtype_size(out_dtype)), VITMI_E_ALIGN, "patchify: out alignment");
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   const int64_t ntok = cls_rows + (H / p) * (W / p);
-  const int64_t total = B * ntok * (C * p * p / 4);
+  const int64_t total = B * ntok * (out_ld / 4);
   const unsigned grid = ew_grid(total);
   if (out_dtype == VITMI_BF16)
-    hipLaunchKernelGGL((patchify_kernel<bf16>), dim3(grid), dim3(EW_BLOCK), 0, stream, x, sb, sc, sh, sw, (bf16*)out, B, (int)C, (int)H, (int)W, (int)p, cls_rows);
+    hipLaunchKernelGGL((patchify_kernel<bf16>), dim3(grid), dim3(EW_BLOCK), 0, stream, x, sb, sc, sh, sw, (bf16*)out, out_ld, B, (int)C, (int)H, (int)W, (int)p, cls_rows);
   else if (out_dtype == VITMI_F32)
-    hipLaunchKernelGGL((patchify_kernel<float>), dim3(grid), dim3(EW_BLOCK), 0, stream, x, sb, sc, sh, sw, (float*)out, B, (int)C, (int)H, (int)W, (int)p, cls_rows);
+    hipLaunchKernelGGL((patchify_kernel<float>), dim3(grid), dim3(EW_BLOCK), 0, stream, x, sb, sc, sh, sw, (float*)out, out_ld, B, (int)C, (int)H, (int)W, (int)p, cls_rows);
   else return vitmi_fail(VITMI_E_DTYPE, "patchify: bad out dtype");
   return vitmi_check_launch("patchify_kernel");
 }

@@ -222,12 +222,14 @@ def cast(src, dst):
 
 
 def patchify(x, out, p, cls_rows):
-    """x [B,C,H,W] fp32 (any strides) -> out [B*(cls_rows+gh*gw), C*p*p]."""
+    """x [B,C,H,W] fp32 (any strides) -> out [B*(cls_rows+gh*gw), ld] with ld >= C*p*p; the columns
+    beyond C*p*p are written as zeros (K padding for the tile GEMM)."""
     _need_cuda(x, out)
-    assert x.dtype == torch.float32 and x.dim() == 4 and out.is_contiguous()
+    assert x.dtype == torch.float32 and x.dim() == 4 and out.dim() == 2 and out.is_contiguous()
     B, Cc, H, W = x.shape
+    assert out.shape[1] >= Cc * p * p and out.shape[1] % 4 == 0
     sb, sc, sh, sw = x.stride()
-    check(load().vitmi_patchify(x.data_ptr(), sb, sc, sh, sw, out.data_ptr(), dtype_code(out),
+    check(load().vitmi_patchify(x.data_ptr(), sb, sc, sh, sw, out.data_ptr(), dtype_code(out), out.shape[1],
                                 B, Cc, H, W, p, int(cls_rows), _stream()), "vitmi_patchify")
     return out
 

@@ -220,6 +220,12 @@ class SwinEngine:
         self.saved = None
         self.reducer = None
         self.profile = None
+        # bf16 patch-embed weight at the padded contraction width (see forward); allocated here so
+        # that it never lands in a graph's private pool
+        Kp = model.patch_embed.proj.weight[0].numel()
+        self._pe_kld = max(64, (Kp + 31) // 32 * 32) if self.T == torch.bfloat16 else Kp
+        self._pe_wpad = (torch.zeros((model.embed_dim, self._pe_kld), dtype=self.T, device=dev)
+                         if self._pe_kld != Kp else None)
         self.gemm_impl = GEMM_AUTO
 
     def is_current(self):
@@ -264,10 +270,19 @@ class SwinEngine:
         C = m.embed_dim
         M = B * Hh * Ww
         Kp = Cin * p * p
-        patches = new(M, Kp, T)
+        # the tile GEMM contracts in steps of 32 and needs K >= 64: Swin's 4x4x3 = 48-wide patches are
+        # written at a padded row stride (the extra columns zero, weight likewise) instead of
+        # falling to the any-shape kernel
+        Kld = self._pe_kld
+        patches = new(M, Kld, T)
         ops.patchify(x, patches, p, cls_rows=0)
         Y = new(M, C, R)
-        self._gemm(patches, self._w(pe.proj.weight).view(C, Kp), Y, bias=pk.f32(pe.proj.bias))
+        if Kld != Kp:
+            ops.scale_cast(pk.f32(pe.proj.weight).view(C, Kp), self._pe_wpad, M=C, N=Kp, ldx=Kp, ldo=Kld)
+            Wpe = self._pe_wpad
+        else:
+            Wpe = self._w(pe.proj.weight).view(C, Kp)
+        self._gemm(patches, Wpe, Y, bias=pk.f32(pe.proj.bias))
         pe_saved = None
         if pe.norm is not None:
             X, meanp, rstdp = new(M, C, R), vec(M), vec(M)
@@ -476,7 +491,8 @@ class SwinEngine:
         # patch embedding (+ its LayerNorm)
         pe = m.patch_embed
         C = m.embed_dim
-        Kp = s["patches"].shape[1]
+        Kld = s["patches"].shape[1]
+        Kp = pe.proj.weight[0].numel()
         M = s["patches"].shape[0]
         if s["pe"] is not None:
             Y, meanp, rstdp = s["pe"]
@@ -487,7 +503,12 @@ class SwinEngine:
             Gb = dYb
         else:
             ops.colsum(Gb, pk.g(pe.proj.bias))
-        self._gemm(Gb, s["patches"], pk.g(pe.proj.weight).view(C, Kp), a_kmajor=False, b_kmajor=False)
+        if Kld != Kp:
+            dWp = torch.empty((C, Kld), dtype=f32, device=Gb.device)
+            self._gemm(Gb, s["patches"], dWp, a_kmajor=False, b_kmajor=False)
+            ops.scale_cast(dWp, pk.g(pe.proj.weight).view(C, Kp), M=C, N=Kp, ldx=Kld, ldo=Kp)
+        else:
+            self._gemm(Gb, s["patches"], pk.g(pe.proj.weight).view(C, Kp), a_kmajor=False, b_kmajor=False)
         self._ready(m.patch_embed)
         if self.reducer is not None:
             self.reducer.finish()
