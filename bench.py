@@ -48,7 +48,9 @@ def parse():
     ap.add_argument("--arch", default="dino_vitb16")
     ap.add_argument("--img", type=int, default=224)
     ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--residual", default="fp32", choices=["bf16", "fp32"])
+    ap.add_argument("--residual", default="bf16", choices=["bf16", "fp32"],
+                    help="dtype of the residual stream between the blocks (bf16 compute only); the line also "
+                         "carries the other choice's rate (`residual_alt`), measured in the same process")
     ap.add_argument("--mode", default="finetune", choices=["finetune", "lineareval"],
                     help="lineareval: frozen backbone under no_grad + a 10-class head trained on its features "
                          "(the reference's --lineareval, main.py:184-201)")
@@ -56,6 +58,7 @@ def parse():
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the step from a captured HIP graph (single GPU; auto = try, fall back to eager)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the run with the other residual-stream dtype")
     ap.add_argument("--force-ddp", action="store_true",
                     help="run the RCCL gradient exchange even in a world of one rank (launcher / ordering test)")
     ap.add_argument("--cpu-batch", type=int, default=16)
@@ -357,6 +360,32 @@ def main():
                               "avg_ms": round(v[2] / v[0] * 1e3, 4),
                               "tflops": round(v[1] / v[2] / 1e12, 1)} for k, v in sorted(rows.items())]}
 
+    # ---- the same step with the OTHER residual-stream dtype (single GPU, bf16 compute): reported beside
+    # `value` so that the cost of the fp32 stream (and the numerics bought with it, `parity`) stays visible
+    alt = None
+    if rank == 0 and not ddp and a.compute == "bf16" and a.mode == "finetune" and not a.no_alt:
+        other = "fp32" if a.residual == "bf16" else "bf16"
+        try:
+            torch.manual_seed(1)
+            m2 = build_model(a.arch, a.img, a.compute, other).to(dev)
+            m2.train()
+            o2 = FusedSGD(m2.parameters(), lr=1e-3, momentum=0.9)
+
+            def step2():
+                o2.zero_grad()
+                l2 = crit(m2(x), y)
+                l2.backward()
+                o2.step()
+
+            n2 = max(5, min(a.steps, 10))
+            quick_ms(step2, 2)                      # allocator and kernel warm-up
+            alt_ms = quick_ms(step2, n2)
+            alt = {"residual_stream": other, "value": round(a.batch / alt_ms * 1e3, 2), "unit": "images/sec",
+                   "ms_per_step": round(alt_ms, 3), "steps": n2, "hip_graph": False}
+            del m2, o2
+        except Exception as e:
+            alt = {"residual_stream": other, "error": f"{type(e).__name__}: {e}"}
+
     cpu = None
     if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a.arch, a.img, a.cpu_batch, a.cpu_steps, a.mode)
@@ -385,7 +414,7 @@ def main():
             "loss": round(loss_value, 5),
             "step_mfma_frac": (round(ips / world * flop_img * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4)
                                if flop_img else None),
-            "roofline": roof, "cpu_baseline": cpu, "parity": parity,
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "residual_alt": alt,
         }
         print(json.dumps(out), flush=True)
     if ddp:

@@ -169,6 +169,34 @@ __device__ __forceinline__ void colsum_T_tile(float* dst, const f32x16 (&acc)[HD
   for (int db = 0; db < HD / 32; ++db) colsum_T_block(dst + db * 32, acc[db], mul, valid, lr, h5);
 }
 
+// Column sums of row pieces held one per lane: lane = (row in group) * CPR + pc holds 8 consecutive
+// columns (pc*8 ..) of its row(s) in v.  The same transposing butterfly over the row bits of the lane
+// index: 7 shuffles, after which lane (rows-bits = e) holds the total of column pc*8 + e over the
+// 8 rows (CPR = 8), or over 16 rows after one more add (CPR = 4: the lanes < 32 hold it).
+template <int CPR>
+__device__ __forceinline__ float piece_colsum8(float (&v)[8], int lane, int* col) {
+  constexpr int LB = CPR == 8 ? 3 : 2;
+  int e = 0;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const int cnt = 4 >> s;
+    const bool up = (lane >> (LB + s)) & 1;
+#pragma unroll
+    for (int i = 0; i < cnt; ++i) {
+      float lo = v[i], hi = v[i + cnt];
+      asm volatile("" : "+v"(lo), "+v"(hi));     // see colsum_T_block
+      const float keep = up ? hi : lo;
+      const float send = up ? lo : hi;
+      v[i] = keep + __shfl_xor(send, 1 << (LB + s), 64);
+    }
+    e += up ? cnt : 0;
+  }
+#pragma unroll
+  for (int bit = LB + 3; bit < 6; ++bit) v[0] += __shfl_xor(v[0], 1 << bit, 64);
+  *col = (lane % CPR) * 8 + e;
+  return v[0];
+}
+
 // rows owned per workgroup / rows streamed per chunk for a block of nw waves
 __device__ __forceinline__ int chunk_rows(int nw) { return 32 * (nw < 4 ? nw : 4); }
 
@@ -676,16 +704,11 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16* __restr
                                                              const bf16* __restrict__ dout,
                                                              const float* __restrict__ lse,
                                                              bf16* __restrict__ dqkv, int N, int H,
-                                                             float scale, float scale_log2e,
+                                                             int npairs, int stagger, float scale, float scale_log2e,
                                                              float* __restrict__ dbias_part,
                                                              unsigned long long* dbg) {
   using C = AttnCfg<HD>;
   using F = FusedBwdCfg<HD>;
-  // diagnostic timeline (armed by tools/attn_bench.py --stamps only): first 64 workgroups
-  const int dbg_slot = (int)blockIdx.x - 1536;     // mid-launch workgroups: steady state, not the cold start
-  const bool dbg_on = dbg != nullptr && dbg_slot >= 0 && dbg_slot < 64;
-  unsigned long long tl[5] = {0, 0, 0, 0, 0};
-  if (dbg_on) tl[0] = attn_stamp();
   constexpr int QS = F::QS, DQS = F::DQS, CPR = HD / 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
@@ -697,50 +720,94 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16* __restr
   char* dQl = dOl + NP * QS;                       // first the K staging, then fp32 dQ
   float* lse_s = reinterpret_cast<float*>(dQl + NP * DQS);
   float* del_s = lse_s + NP;
-  char* Tl = reinterpret_cast<char*>(del_s + NP) + w * 32 * F::TPITCH;
-  const int bh = blockIdx.x, b = bh / H, h = bh % H;
+  char* Tbase = reinterpret_cast<char*>(del_s + NP);
+  char* Tl = Tbase + w * 32 * F::TPITCH;
   const int64_t ts = (int64_t)3 * H * HD;
   const int64_t os = (int64_t)H * HD;
-  const bf16* qb = qkv + (int64_t)b * N * ts + h * HD;
-  const bf16* kb_ = qb + H * HD;
-  const bf16* vb = qb + 2 * H * HD;
-  const bf16* dob = dout + (int64_t)b * N * os + h * HD;
-  const bf16* ob = out + (int64_t)b * N * os + h * HD;
   const int key = w * 32 + lr;
   const int krow = min(key, N - 1);
+  const bool kvalid = key < N;
 
-  bf16x8 vf[C::KSTEPS];                            // B[k = d][n = key] of dP = dO V^T
-#pragma unroll
-  for (int s = 0; s < C::KSTEPS; ++s)
-    vf[s] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)krow * ts + 16 * s + 8 * h5);
-
-  // ---- stage Q, dO (and delta = rowsum(dO * O)), K; rows >= N are zero.  NP*CPR pieces of
-  // 16 B over nthr = NP*2 threads = CPR/2 pieces per thread and matrix: ALL the loads are
-  // issued before the first LDS store (one HBM round trip, not one per piece).
+  // ---- PERSISTENT walk over (image, head) pairs: a workgroup owns the whole CU (LDS), so the
+  // only thing that can run beside its memory phases is its own next pair.  The global loads
+  // of pair i+1 (Q, K, dO, O pieces, lse, the V fragments: one batch, registers) are issued
+  // right after the loop of pair i, BEFORE its dQ / dK / dV rows are written out: the HBM
+  // round trip of the staging runs under the store phase instead of after it.
+  // NP*CPR pieces of 16 B over nthr = NP*2 threads = CPR/2 pieces per thread and matrix.
   constexpr int IT = CPR / 2;
+  bf16x8 vf[C::KSTEPS];                            // B[k = d][n = key] of dP = dO V^T
   bf16x8 q8[IT], d8[IT], o8[IT], k8[IT];
   float lv[IT];
+  auto issue_loads = [&](int bh) {
+    const int b = bh / H, h = bh % H;
+    const bf16* qb = qkv + (int64_t)b * N * ts + h * HD;
+    const bf16* kb_ = qb + H * HD;
+    const bf16* dob = dout + (int64_t)b * N * os + h * HD;
+    const bf16* ob = out + (int64_t)b * N * os + h * HD;
+    // the per-lane offsets are the same for every pair: hidden from the optimizer, or it keeps
+    // ~40 registers of hoisted addresses alive across the main loop (spills)
+    int tid_o = tid;
+    asm volatile("" : "+v"(tid_o));
 #pragma unroll
-  for (int i = 0; i < IT; ++i) {
-    // unconditional loads from a clamped row (a branch around a load makes hipcc wait for
-    // each one separately); rows >= N are zeroed by the selects below
-    const int c = tid + i * nthr, row = min(c / CPR, N - 1), pc = c % CPR;
-    q8[i] = *reinterpret_cast<const bf16x8*>(qb + (int64_t)row * ts + pc * 8);
-    k8[i] = *reinterpret_cast<const bf16x8*>(kb_ + (int64_t)row * ts + pc * 8);
-    d8[i] = *reinterpret_cast<const bf16x8*>(dob + (int64_t)row * os + pc * 8);
-    o8[i] = *reinterpret_cast<const bf16x8*>(ob + (int64_t)row * os + pc * 8);
-    lv[i] = lse[(int64_t)bh * N + row];           // with the batch: a load in the store loop would drain it each time
+    for (int i = 0; i < IT; ++i) {
+      // unconditional loads from a clamped row (a branch around a load makes hipcc wait for
+      // each one separately); rows >= N are zeroed by the selects of the commit
+      const int c = tid_o + i * nthr, row = min(c / CPR, N - 1), pc = c % CPR;
+      q8[i] = *reinterpret_cast<const bf16x8*>(qb + (int64_t)row * ts + pc * 8);
+      k8[i] = *reinterpret_cast<const bf16x8*>(kb_ + (int64_t)row * ts + pc * 8);
+      d8[i] = *reinterpret_cast<const bf16x8*>(dob + (int64_t)row * os + pc * 8);
+      o8[i] = *reinterpret_cast<const bf16x8*>(ob + (int64_t)row * os + pc * 8);
+      lv[i] = lse[(int64_t)bh * N + row];         // with the batch: a load in the store loop would drain it each time
+    }
+    // hipcc sinks a load whose only use sits under `if (pc == 0)` into that branch, behind the
+    // wait for the batch: a second HBM round trip.  An opaque use keeps all of them up here.
+#pragma unroll
+    for (int i = 0; i < IT; ++i) asm volatile("" : "+v"(lv[i]));
+  };
+
+  int bh = blockIdx.x;
+  if (bh >= npairs) return;
+  // every other workgroup of an XCD starts `stagger` x 1k cycles late (persistent grids only): the
+  // memory phases of one half of the chip then fall into the compute phases of the other half
+  if (stagger > 0 && ((blockIdx.x >> 3) & 1))
+    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(16);
+  issue_loads(bh);
+
+#pragma unroll 1
+  for (;;) {
+  const int b = bh / H, h = bh % H;
+  // diagnostic timeline (armed by tools/attn_bench.py --stamps only): 64 mid-launch pairs
+  const int dbg_slot = bh - npairs / 2;            // steady state, not the cold start
+  const bool dbg_on = dbg != nullptr && dbg_slot >= 0 && dbg_slot < 64;
+  unsigned long long tl[5] = {0, 0, 0, 0, 0};
+  if (dbg_on) tl[0] = attn_stamp();
+  // V fragments of the own keys straight from memory (first used in the main loop: their round
+  // trip runs under the commit; staged a pair ahead they would cost 16 registers across it)
+  {
+    const bf16* vb = qkv + (int64_t)b * N * ts + (2 * H + h) * HD;
+    int krow_o = krow;
+    asm volatile("" : "+v"(krow_o));
+#pragma unroll
+    for (int s = 0; s < C::KSTEPS; ++s)
+      vf[s] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)krow_o * ts + 16 * s + 8 * h5);
   }
-  // hipcc sinks a load whose only use sits under `if (pc == 0)` into that branch, behind the
-  // wait for the batch: a second HBM round trip.  An opaque use keeps all of them up here.
-#pragma unroll
-  for (int i = 0; i < IT; ++i) asm volatile("" : "+v"(lv[i]));
+
+  // ---- commit the staged registers: Q, dO (and delta = rowsum(dO * O)), K; rows >= N are zero
+  // (per-lane offsets of the memory phases derive from an opaque copy of tid: left visible, the
+  // optimizer hoists them out of the pair loop and they sit in registers across the main loop)
+  int tid_c = tid;
+  asm volatile("" : "+v"(tid_c));
+  float dosum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < IT; ++i) {
-    const int c = tid + i * nthr, row = c / CPR, pc = c % CPR;
+    const int c = tid_c + i * nthr, row = c / CPR, pc = c % CPR;
     if (row >= N) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) { q8[i][e] = (bf16)0.f; d8[i][e] = (bf16)0.f; k8[i][e] = (bf16)0.f; }
+    }
+    if constexpr (DBIAS) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dosum[e] += (float)d8[i][e];
     }
     *reinterpret_cast<bf16x8*>(Ql + row * QS + pc * 16) = q8[i];
     *reinterpret_cast<bf16x8*>(dOl + row * QS + pc * 16) = d8[i];
@@ -755,6 +822,14 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16* __restr
       lse_s[row] = row < N ? lv[i] * LOG2E : INFINITY;    // +inf -> p = 0 for padded queries
     }
   }
+  // qkv-bias gradient of this (image, head) without touching the accumulators:
+  //   v: sum_k dV[k,:] = (P 1)^T dO = 1^T dO   (softmax rows sum to one): column sums of dO, taken
+  //      here from the staged pieces (one value per lane, kept across the main loop);
+  //   k: sum_k dK[k,:] = sum_q (sum_k dS[q,k]) Q[q,:] = 0   (sum_k P (dP - delta) = delta - delta);
+  //   q: column sums of dQ, taken while its rows are converted for the store.
+  float dvb = 0.f;
+  int dvb_col = 0;
+  if constexpr (DBIAS) dvb = piece_colsum8<CPR>(dosum, tid_c & 63, &dvb_col);
   __syncthreads();
   if (dbg_on) tl[1] = attn_stamp();
   bf16x8 kf[C::KSTEPS];                            // B[k = d][n = key] of S = Q K^T
@@ -776,7 +851,6 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16* __restr
   f32x16 dk[C::DB], dv[C::DB];
 #pragma unroll
   for (int db = 0; db < C::DB; ++db) { zero16(dk[db]); zero16(dv[db]); }
-  const bool kvalid = key < N;
   if (dbg_on) tl[2] = attn_stamp();
 
 #pragma unroll 1
@@ -888,45 +962,48 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16* __restr
   if (dbg_on) tl[3] = attn_stamp();
   // dK, dV: transposed accumulators (lane = key, 4 consecutive d per register run) -> bf16
   // rows in the dead Q / dO images, so that every global store below is a 16-B piece of a
-  // 128-B row segment (a lane-per-row store tail is issue-bound: guide, 'epilogue store tail')
-  store_T_tile<HD>(reinterpret_cast<bf16*>(Ql + key * QS), dk, scale, h5);
-  store_T_tile<HD>(reinterpret_cast<bf16*>(dOl + key * QS), dv, 1.f, h5);
+  // 128-B row segment (a lane-per-row store tail is issue-bound: guide, 'epilogue store tail').
+  int tid_s = tid;
+  asm volatile("" : "+v"(tid_s));
+  const int lr_s = tid_s & 31, h5_s = (tid_s >> 5) & 1, key_s = w * 32 + lr_s;
+  store_T_tile<HD>(reinterpret_cast<bf16*>(Ql + key_s * QS), dk, scale, h5_s);
+  store_T_tile<HD>(reinterpret_cast<bf16*>(dOl + key_s * QS), dv, 1.f, h5_s);
+  float* red = reinterpret_cast<float*>(Tbase);    // the dS tiles are dead: [2][nw][HD] partial sums
   __syncthreads();
-  for (int c = tid; c < N * CPR; c += nthr) {
+  const int bh_next = bh + (int)gridDim.x;
+  // unconditional (the last pair loads itself again, unused): under a branch the staged registers
+  // of THIS pair would stay live across the main loop as the other input of the merge (spills)
+  issue_loads(min(bh_next, npairs - 1));
+  float dqsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int c = tid_s; c < N * CPR; c += nthr) {
     const int row = c / CPR, pc = c % CPR;
     bf16* grow = dqkv + (int64_t)(b * (int64_t)N + row) * ts + h * HD + pc * 8;
     const f32x4 a = *reinterpret_cast<const f32x4*>(dQl + row * DQS + pc * 32);
     const f32x4 b4 = *reinterpret_cast<const f32x4*>(dQl + row * DQS + pc * 32 + 16);
-    bf16x8 o8;
+    bf16x8 o8s;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { o8[e] = (bf16)(a[e] * scale); o8[4 + e] = (bf16)(b4[e] * scale); }
-    *reinterpret_cast<bf16x8*>(grow) = o8;
+    for (int e = 0; e < 4; ++e) {
+      const float x0 = a[e] * scale, x1 = b4[e] * scale;
+      o8s[e] = (bf16)x0; o8s[4 + e] = (bf16)x1;
+      if constexpr (DBIAS) { dqsum[e] += x0; dqsum[4 + e] += x1; }
+    }
+    *reinterpret_cast<bf16x8*>(grow) = o8s;
     *reinterpret_cast<bf16x8*>(grow + H * HD) = *reinterpret_cast<const bf16x8*>(Ql + row * QS + pc * 16);
     *reinterpret_cast<bf16x8*>(grow + 2 * H * HD) = *reinterpret_cast<const bf16x8*>(dOl + row * QS + pc * 16);
   }
   if constexpr (DBIAS) {
-    // column sums of dQ / dK / dV of this (image, head): the qkv-bias gradient partials
-    __syncthreads();                               // the dK / dV rows have been read back
-    float* red = reinterpret_cast<float*>(Ql);
-    colsum_T_tile<HD>(red + (w * 2 + 0) * HD, dk, scale, kvalid, lr, h5);
-    colsum_T_tile<HD>(red + (w * 2 + 1) * HD, dv, 1.f, kvalid, lr, h5);
-    float* redq = red + nw * 2 * HD;
-    const int P = nthr / HD;
-    {
-      const int col = tid % HD, part = tid / HD;
-      float t = 0.f;
-      for (int row = part; row < N; row += P) t += *reinterpret_cast<const float*>(dQl + row * DQS + col * 4);
-      redq[part * HD + col] = t * scale;
+    int dqb_col;
+    const float dqb = piece_colsum8<CPR>(dqsum, tid_s & 63, &dqb_col);
+    if (CPR == 8 || (tid_s & 63) < 32) {
+      red[w * HD + dqb_col] = dqb;
+      red[(nw + w) * HD + dvb_col] = dvb;
     }
     __syncthreads();
-    for (int i = tid; i < 3 * HD; i += nthr) {
+    for (int i = tid_s; i < 3 * HD; i += nthr) {
       const int which = i / HD, d = i % HD;
       float t = 0.f;
-      if (which == 0) {
-        for (int pp = 0; pp < P; ++pp) t += redq[pp * HD + d];
-      } else {
-        for (int ww = 0; ww < nw; ++ww) t += red[(ww * 2 + which - 1) * HD + d];
-      }
+      if (which != 1)
+        for (int ww = 0; ww < nw; ++ww) t += red[((which >> 1) * nw + ww) * HD + d];
       dbias_part[(int64_t)b * ts + which * H * HD + h * HD + d] = t;
     }
   }
@@ -935,6 +1012,10 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16* __restr
     tl[4] = attn_stamp();
     if (tid == 0)
       for (int i = 0; i < 5; ++i) dbg[dbg_slot * 8 + i] = tl[i];
+  }
+  if (bh_next >= npairs) break;
+  bh = bh_next;
+  __syncthreads();                                 // every read of the images is done: the commit may overwrite them
   }
 }
 
@@ -1008,6 +1089,8 @@ static unsigned long long* g_attn_dbg = nullptr;
 extern "C" void vitmi_debug_attn_stamps(void* p) { g_attn_dbg = reinterpret_cast<unsigned long long*>(p); }
 static int g_attn_bwd_mode = -1;     // diagnostic / test hook: 0 = dkdv + dq kernels, 1 = fused where possible
 extern "C" void vitmi_debug_attn_bwd(int mode) { g_attn_bwd_mode = mode; }
+static int g_attn_stagger = 0;       // diagnostic hook: late start of every other workgroup, in units of ~1k cycles
+extern "C" void vitmi_debug_attn_stagger(int k) { g_attn_stagger = k; }
 static bool attn_bwd_fused_ok(int64_t N, int64_t hd) {
   if (g_attn_bwd_mode == 0) return false;
   const int nw = attn_waves(N);
@@ -1037,14 +1120,18 @@ extern "C" int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout
   const int64_t rows = B * N * H;
   const int nw = attn_waves(N);
   if (attn_bwd_fused_ok(N, hd)) {
+    // one workgroup per CU walking pairs bh, bh + grid, ... (see the kernel); one pair per workgroup
+    // when persistent grids are off (data-parallel runs: RCCL kernels hold CUs)
+    const int64_t grid_f = vitmi_persist_on() && B * H > vitmi_cu_count() ? vitmi_cu_count() : B * H;
 #define LAUNCH_FUSED(HDV, DB)                                                                            \
     do {                                                                                                 \
       auto kern = attn_bwd_fused_kernel<HDV, DB>;                                                        \
       const size_t lds = (size_t)nw * 32 * FusedBwdCfg<HDV>::ROW_BYTES;                                  \
       if (int rc_ = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024, "attn_bwd")) return rc_; \
-      hipLaunchKernelGGL(kern, dim3((unsigned)(B * H)), dim3(64 * nw), lds, stream, (const bf16*)qkv,    \
-                         (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, (int)N, (int)H, scale,   \
-                         scale * LOG2E, dbias_part, g_attn_dbg);                                         \
+      hipLaunchKernelGGL(kern, dim3((unsigned)grid_f), dim3(64 * nw), lds, stream, (const bf16*)qkv,     \
+                         (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, (int)N, (int)H,          \
+                         (int)(B * H), grid_f < B * H ? g_attn_stagger : 0, scale, scale * LOG2E,        \
+                         dbias_part, g_attn_dbg);                                                        \
     } while (0)
     if (hd == 64) { if (dbias_part) LAUNCH_FUSED(64, true); else LAUNCH_FUSED(64, false); }
     else          { if (dbias_part) LAUNCH_FUSED(32, true); else LAUNCH_FUSED(32, false); }

@@ -2,6 +2,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <map>
+#include <atomic>
 #include <mutex>
 #include <set>
 #include <utility>
@@ -49,6 +50,10 @@ int vitmi_cu_count() {
   g_cus[dev] = cus;
   return cus;
 }
+
+static std::atomic<int> g_persist{1};
+extern "C" void vitmi_debug_gemm_persist(int on) { g_persist.store(on, std::memory_order_relaxed); }
+int vitmi_persist_on() { return g_persist.load(std::memory_order_relaxed); }
 
 int vitmi_raise_dynamic_lds(const void* kern, int bytes, const char* who) {
   const int dev = current_device();

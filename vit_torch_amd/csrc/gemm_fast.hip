@@ -855,11 +855,9 @@ template <int MODE, typename TC, bool SPLITK, int PIPE>
 constexpr int lds_bytes() {
   return SPLITK ? 2 * STAGE_BYTES : RF_LDS;
 }
-static int g_persist = 1;
-// diagnostic / test hook: 0 = one tile per workgroup (grid = tiles), 1 = persistent grid (one workgroup per CU)
-extern "C" void vitmi_debug_gemm_persist(int on) { g_persist = on; }
+// vitmi_debug_gemm_persist (core.cpp): 0 = one tile per workgroup (grid = tiles), 1 = persistent grid
 static int persistent_grid(int nwg) {
-  if (!g_persist) return nwg;
+  if (!vitmi_persist_on()) return nwg;
   int cus = vitmi_cu_count();
   cus -= cus % 8;                                  // whole XCD rows: every XCD gets the same number of workgroups
   if (cus < 8) cus = 8;
