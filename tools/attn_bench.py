@@ -41,11 +41,6 @@ for spec in specs:
             tb = timed(lambda: ops.attn_bwd(qkv, O, do, lse, dqkv, B, N, H, hd, scale, dbias_part=part))
             print(f"   bwd[{name}] {tb:7.1f} us ({2.5 * fl / tb / 1e6:6.1f} TF)")
     raw.vitmi_debug_attn_bwd(1)
-    for stg in (0, 6, 12, 18, 24, 0):
-        raw.vitmi_debug_attn_stagger(stg)
-        tb = timed(lambda: ops.attn_bwd(qkv, O, do, lse, dqkv, B, N, H, hd, scale, dbias_part=part))
-        print(f"   bwd[fused, stagger {stg}k] {tb:7.1f} us")
-    raw.vitmi_debug_attn_stagger(0)
     for rnd in range(2):
         tb = timed(lambda: ops.attn_bwd(qkv, O, do, lse, dqkv, B, N, H, hd, scale, dbias_part=None))
         print(f"   bwd[fused, no bias sums] {tb:7.1f} us")

@@ -704,7 +704,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16* __restr
                                                              const bf16* __restrict__ dout,
                                                              const float* __restrict__ lse,
                                                              bf16* __restrict__ dqkv, int N, int H,
-                                                             int npairs, int stagger, float scale, float scale_log2e,
+                                                             int npairs, float scale, float scale_log2e,
                                                              float* __restrict__ dbias_part,
                                                              unsigned long long* dbg) {
   using C = AttnCfg<HD>;
@@ -767,10 +767,6 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16* __restr
 
   int bh = blockIdx.x;
   if (bh >= npairs) return;
-  // every other workgroup of an XCD starts `stagger` x 1k cycles late (persistent grids only): the
-  // memory phases of one half of the chip then fall into the compute phases of the other half
-  if (stagger > 0 && ((blockIdx.x >> 3) & 1))
-    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(16);
   issue_loads(bh);
 
 #pragma unroll 1
@@ -1089,8 +1085,6 @@ static unsigned long long* g_attn_dbg = nullptr;
 extern "C" void vitmi_debug_attn_stamps(void* p) { g_attn_dbg = reinterpret_cast<unsigned long long*>(p); }
 static int g_attn_bwd_mode = -1;     // diagnostic / test hook: 0 = dkdv + dq kernels, 1 = fused where possible
 extern "C" void vitmi_debug_attn_bwd(int mode) { g_attn_bwd_mode = mode; }
-static int g_attn_stagger = 0;       // diagnostic hook: late start of every other workgroup, in units of ~1k cycles
-extern "C" void vitmi_debug_attn_stagger(int k) { g_attn_stagger = k; }
 static bool attn_bwd_fused_ok(int64_t N, int64_t hd) {
   if (g_attn_bwd_mode == 0) return false;
   const int nw = attn_waves(N);
@@ -1130,8 +1124,7 @@ extern "C" int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout
       if (int rc_ = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024, "attn_bwd")) return rc_; \
       hipLaunchKernelGGL(kern, dim3((unsigned)grid_f), dim3(64 * nw), lds, stream, (const bf16*)qkv,     \
                          (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, (int)N, (int)H,          \
-                         (int)(B * H), grid_f < B * H ? g_attn_stagger : 0, scale, scale * LOG2E,        \
-                         dbias_part, g_attn_dbg);                                                        \
+                         (int)(B * H), scale, scale * LOG2E, dbias_part, g_attn_dbg);                    \
     } while (0)
     if (hd == 64) { if (dbias_part) LAUNCH_FUSED(64, true); else LAUNCH_FUSED(64, false); }
     else          { if (dbias_part) LAUNCH_FUSED(32, true); else LAUNCH_FUSED(32, false); }
