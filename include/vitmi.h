@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VITMI_VERSION 102
+#define VITMI_VERSION 103
 
 enum { VITMI_F32 = 0, VITMI_BF16 = 1 };
 
@@ -114,6 +114,12 @@ typedef struct vitmi_gemm_desc {
    * is not read back from HBM just to be summed.  Ask vitmi_gemm_uses_fast() first: any
    * other path rejects a non-NULL colsum_part. */
   float* colsum_part;
+  /* EPI_BIAS_GELU / EPI_DGELU pair: 0 -> C2 / AUX hold the pre-activation (as above);
+   * 1 -> EPI_BIAS_GELU stores gelu_erf'(acc+bias) in C2 (it shares the forward's exp) and
+   * EPI_DGELU computes C = acc * AUX: the backward epilogue is a multiply instead of a second
+   * erf/exp evaluation.  Same function of the same pre-activation either way
+   * (torch.nn.GELU backward); a C2 written with one value must be read with the same. */
+  int32_t aux_is_derivative;
 } vitmi_gemm_desc;
 
 int vitmi_gemm(const vitmi_gemm_desc* d, void* stream);

@@ -108,6 +108,12 @@ def test_gemm_epilogues(ops, dt):
     Dg = torch.empty((M, N), device="cuda", dtype=dt)
     ops.gemm(A, B, Dg, epilogue=EPI_DGELU, aux=dev(aux, dt), impl=GEMM_GENERIC)
     assert_close("dgelu", Dg, acc * gelu_grad(aux), tol)
+    # the pair with the derivative kept instead of the pre-activation (aux_is_derivative)
+    ops.gemm(A, B, H, epilogue=EPI_BIAS_GELU, bias=bias_d, C2=P, impl=GEMM_GENERIC, aux_deriv=True)
+    assert_close("gelu[deriv]", H, F.gelu(acc + bias), tol)
+    assert_close("gelu'[deriv]", P, gelu_grad(acc + bias), tol)
+    ops.gemm(A, B, Dg, epilogue=EPI_DGELU, aux=dev(aux, dt), impl=GEMM_GENERIC, aux_deriv=True)
+    assert_close("dgelu[deriv]", Dg, acc * aux, tol)
     # patch + pos (+cls): M = 6 images x 25 tokens
     n_tok = 25
     pos, cls = gen((n_tok, N), 10), gen((N,), 11)
@@ -510,6 +516,12 @@ def test_gemm_ragged_epilogues(ops):
     Dg = torch.empty((M, N), device="cuda", dtype=bt)
     ops.gemm(A, Bt, Dg, b_kmajor=False, epilogue=EPI_DGELU, aux=dev(aux, bt), impl=GEMM_FAST)
     assert_close("dgelu", Dg, acc * gelu_grad(aux), TOL[bt])
+    ops.gemm(A, B, H, epilogue=EPI_BIAS_GELU, bias=bias_d, C2=P, impl=GEMM_FAST, aux_deriv=True)
+    assert_close("gelu[deriv]", H, F.gelu(acc + bias), TOL[bt])
+    assert_close("gelu'[deriv]", P, gelu_grad(acc + bias), TOL[bt])
+    Dd = torch.empty_like(Dg)
+    ops.gemm(A, Bt, Dd, b_kmajor=False, epilogue=EPI_DGELU, aux=dev(aux, bt), impl=GEMM_FAST, aux_deriv=True)
+    assert_close("dgelu[deriv]", Dd, acc * aux, TOL[bt])
     # fused bias gradient on a ragged shape: partial rows of 128, the last one short
     part = torch.full(((M + 127) // 128, N), float("nan"), device="cuda")
     Dg2 = torch.empty_like(Dg)
@@ -604,6 +616,13 @@ def test_gemm_fast_epilogues(ops, pipe):
     Dg = torch.empty((M, N), device="cuda", dtype=bt)
     ops.gemm(A, Bt, Dg, b_kmajor=False, epilogue=EPI_DGELU, aux=dev(aux, bt), impl=GEMM_FAST)
     assert_close("dgelu", Dg, acc * gelu_grad(aux), tol)
+    # the pair with the derivative kept instead of the pre-activation (aux_is_derivative)
+    ops.gemm(A, B, H, epilogue=EPI_BIAS_GELU, bias=bias_d, C2=P, impl=GEMM_FAST, aux_deriv=True)
+    assert_close("gelu[deriv]", H, F.gelu(acc + bias), tol)
+    assert_close("gelu'[deriv]", P, gelu_grad(acc + bias), tol)
+    Dd = torch.empty_like(Dg)
+    ops.gemm(A, Bt, Dd, b_kmajor=False, epilogue=EPI_DGELU, aux=dev(aux, bt), impl=GEMM_FAST, aux_deriv=True)
+    assert_close("dgelu[deriv]", Dd, acc * aux, tol)
     # fused bias gradient: column sums per 128-row group (256x256-tile path only)
     from vit_torch_amd import _lib
     if ops.gemm_uses_fast(M, N, K, b_kmajor=False, epilogue=EPI_DGELU, colsum_part=True):

@@ -38,6 +38,7 @@ class GemmDesc(C.Structure):
         ("a_bs", c_i64 * 2), ("b_bs", c_i64 * 2), ("c_bs", c_i64 * 2),
         ("rowscale", c_vp), ("rows_per_group", c_i64),
         ("colsum_part", c_vp),
+        ("aux_is_derivative", c_i32),
     ]
 
     def __init__(self, *a, **k):

@@ -16,6 +16,7 @@ struct EpiArgs {
   int accumulate;
   const float* rowscale; int64_t rpg;      // RESIDUAL: per-row-group branch scale (DropPath)
   float* colsum_part;                      // DGELU, fast path: [M/128][N] column sums of C
+  int aux_deriv;                           // GELU: C2 = gelu'(pre) instead of pre; DGELU: C = acc * AUX
 };
 
 struct GemmArgs {
@@ -53,6 +54,10 @@ __device__ __forceinline__ float epi_value(const EpiArgs& e, int64_t m, int64_t 
     float pre = acc + (e.bias ? e.bias[n] : 0.f);
     // the backward pass differentiates at the STORED pre-activation, so
     // round it first when C2 is bf16 (keeps fwd and bwd consistent)
+    if (e.aux_deriv) {
+      *v2 = dgelu_erf(pre);
+      return gelu_erf(pre);
+    }
     if (e.c_bf16) pre = (float)(bf16)pre;
     *v2 = pre;
     return gelu_erf(pre);
@@ -63,7 +68,8 @@ __device__ __forceinline__ float epi_value(const EpiArgs& e, int64_t m, int64_t 
     if (e.rowscale) v *= e.rowscale[m / e.rpg];
     return ld_any(e.R, m * e.ldr + n, e.r_bf16) + v;
   } else if constexpr (MODE == VITMI_EPI_DGELU) {
-    return acc * dgelu_erf(ld_any(e.AUX, m * e.ldaux + n, e.aux_bf16));
+    const float aux = ld_any(e.AUX, m * e.ldaux + n, e.aux_bf16);
+    return acc * (e.aux_deriv ? aux : dgelu_erf(aux));
   } else {  // VITMI_EPI_PATCH_POS
     const int64_t t = m % e.n_tok;
     if (t == 0 && e.cls) return e.cls[n] + e.pos[n];

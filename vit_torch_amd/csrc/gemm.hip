@@ -188,6 +188,7 @@ static int build_args(const vitmi_gemm_desc* d, GemmArgs* out) {
   e.R = d->R; e.ldr = d->ldr; e.r_bf16 = d->r_dtype == VITMI_BF16;
   e.gamma = d->gamma;
   e.AUX = d->AUX; e.ldaux = d->ldaux; e.aux_bf16 = d->in_dtype == VITMI_BF16;
+  e.aux_deriv = d->aux_is_derivative != 0;
   e.pos = d->pos; e.n_tok = d->n_tok; e.ldpos = d->N; e.cls = d->cls;
   e.alpha = d->alpha == 0.f ? 1.f : d->alpha;
   e.accumulate = d->accumulate;

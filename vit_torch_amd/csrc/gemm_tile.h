@@ -95,6 +95,18 @@ __device__ __forceinline__ f32x2 gelu2(f32x2 x) {
   r[1] = __builtin_fmaf(-__builtin_fabsf(x[1]), h[1], __builtin_fmaxf(x[1], 0.f));
   return r;
 }
+// gelu and gelu' of the same argument from one tail evaluation (aux_is_derivative forward)
+__device__ __forceinline__ void gelu_both2(f32x2 x, f32x2* gl, f32x2* dg) {
+  f32x2 h, e, r;
+  gelu_tail2(x, &h, &e);
+  r[0] = __builtin_fmaf(-__builtin_fabsf(x[0]), h[0], __builtin_fmaxf(x[0], 0.f));
+  r[1] = __builtin_fmaf(-__builtin_fabsf(x[1]), h[1], __builtin_fmaxf(x[1], 0.f));
+  f32x2 d = 0.5f - h;
+  d[0] = __builtin_copysignf(d[0], x[0]);
+  d[1] = __builtin_copysignf(d[1], x[1]);
+  *gl = r;
+  *dg = (d + 0.5f) + (x * e) * 0.39894228040143267794f;
+}
 __device__ __forceinline__ f32x2 dgelu2(f32x2 x) {
   f32x2 h, e;
   gelu_tail2(x, &h, &e);
@@ -183,13 +195,23 @@ __device__ __forceinline__ void epi_row(const EpiArgs& e, int64_t mu, int64_t ml
     }
   } else if constexpr (MODE == VITMI_EPI_BIAS_GELU) {
     float pre[W];
+    if (e.aux_deriv) {                       // wave-uniform: C2 = gelu'(acc + bias)
 #pragma unroll
-    for (int i = 0; i < W; i += 2) {
-      f32x2 p = {v[i] + b[i], v[i + 1] + b[i + 1]};
-      if constexpr (sizeof(TC) == 2) { p[0] = (float)(bf16)p[0]; p[1] = (float)(bf16)p[1]; }
-      const f32x2 r = gelu2(p);
-      pre[i] = p[0]; pre[i + 1] = p[1];
-      v[i] = r[0]; v[i + 1] = r[1];
+      for (int i = 0; i < W; i += 2) {
+        f32x2 r, d;
+        gelu_both2(f32x2{v[i] + b[i], v[i + 1] + b[i + 1]}, &r, &d);
+        pre[i] = d[0]; pre[i + 1] = d[1];
+        v[i] = r[0]; v[i + 1] = r[1];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < W; i += 2) {
+        f32x2 p = {v[i] + b[i], v[i + 1] + b[i + 1]};
+        if constexpr (sizeof(TC) == 2) { p[0] = (float)(bf16)p[0]; p[1] = (float)(bf16)p[1]; }
+        const f32x2 r = gelu2(p);
+        pre[i] = p[0]; pre[i + 1] = p[1];
+        v[i] = r[0]; v[i + 1] = r[1];
+      }
     }
     if (e.C2) storev<TC, W>(reinterpret_cast<TC*>(e.C2) + row_off(mu, ml, e.ldc2, n), pre);
   } else if constexpr (MODE == VITMI_EPI_RESIDUAL) {
@@ -204,10 +226,15 @@ __device__ __forceinline__ void epi_row(const EpiArgs& e, int64_t mu, int64_t ml
 #pragma unroll
     for (int i = 0; i < W; ++i) v[i] = x[i] + rs * gm[i] * (v[i] + b[i]);
   } else if constexpr (MODE == VITMI_EPI_DGELU) {
+    if (e.aux_deriv) {                       // wave-uniform: AUX is gelu'(pre) already
 #pragma unroll
-    for (int i = 0; i < W; i += 2) {
-      const f32x2 d = dgelu2(f32x2{x[i], x[i + 1]});
-      v[i] *= d[0]; v[i + 1] *= d[1];
+      for (int i = 0; i < W; ++i) v[i] *= x[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < W; i += 2) {
+        const f32x2 d = dgelu2(f32x2{x[i], x[i + 1]});
+        v[i] *= d[0]; v[i + 1] *= d[1];
+      }
     }
   } else {  // PATCH_POS
     const int64_t t = m % e.n_tok;

@@ -51,7 +51,7 @@ def workspace(nbytes: int, device) -> torch.Tensor:
 
 def gemm(A, B, C_out, *, a_kmajor=True, b_kmajor=True, epilogue=EPI_STORE, bias=None, R=None,
          gamma=None, aux=None, C2=None, pos=None, n_tok=0, cls=None, alpha=1.0, accumulate=False,
-         impl=GEMM_AUTO, rowscale=None, rows_per_group=0, colsum_part=None):
+         impl=GEMM_AUTO, rowscale=None, rows_per_group=0, colsum_part=None, aux_deriv=False):
     """C = epilogue(op(A) @ op(B)^T); see vitmi_gemm in include/vitmi.h."""
     _need_cuda(A, B, C_out)
     assert A.dim() == 2 and B.dim() == 2 and C_out.dim() == 2
@@ -100,6 +100,7 @@ def gemm(A, B, C_out, *, a_kmajor=True, b_kmajor=True, epilogue=EPI_STORE, bias=
         assert colsum_part.dtype == torch.float32 and colsum_part.is_contiguous()
         assert tuple(colsum_part.shape) == ((M + 127) // 128, N)
         d.colsum_part = colsum_part.data_ptr()
+    d.aux_is_derivative = int(bool(aux_deriv))
     lib = load()
     need = lib.vitmi_gemm_workspace(C.byref(d))
     if need:

@@ -166,6 +166,11 @@ def _head_layers(head) -> Optional[List[tuple]]:
 def engine_gemm(eng, A, B, C, **k):
     """ops.gemm with the engine's implementation switch; when eng.profile is a list, each
     launch is bracketed by HIP events on the launch stream (bench.py's roofline leg)."""
+    # the block MLPs keep gelu'(pre) instead of pre in bf16 mode: the GELU epilogue has the exp
+    # at hand, and the backward epilogue becomes a multiply (vitmi_gemm_desc.aux_is_derivative).
+    # fp32 (parity) mode keeps the pre-activation, as the reference's autograd does.
+    if k.get("epilogue") in (EPI_BIAS_GELU, EPI_DGELU):
+        k.setdefault("aux_deriv", eng.T == torch.bfloat16)
     if eng.profile is None:
         return ops.gemm(A, B, C, impl=eng.gemm_impl, **k)
     akm, bkm = k.get("a_kmajor", True), k.get("b_kmajor", True)
@@ -320,7 +325,7 @@ class VitEngine:
             ops.layernorm_fwd(X1, self.pack.f32(blk.norm2.weight), self.pack.f32(blk.norm2.bias), ln2,
                               mean2, rstd2, blk.norm2.eps, M=M, D=D)
             Dh = mlp.fc1.out_features
-            pre = new(M, Dh, T)
+            pre = new(M, Dh, T) if save else None       # what the backward needs of fc1's output (engine_gemm)
             hid = new(M, Dh, T)
             self._gemm(ln2, self._w(mlp.fc1.weight), hid, epilogue=EPI_BIAS_GELU,
                        bias=self.pack.f32(mlp.fc1.bias), C2=pre)
