@@ -1,12 +1,13 @@
 #!/bin/bash
 # usage (on the GPU box): tools/pmc_gemm_shapes.sh <tag>
-# Per-shape HBM traffic of the twelve GEMMs of a ViT-B/16 block (bs 256), each with its real epilogue:
+# Per-shape HBM traffic of the twelve GEMMs of a ViT-B/16 block (bs 256), each with its real epilogue
+# (bf16 residual stream, the benchmarked mode):
 # two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) per shape, no trace domains; summarised
 # against the algorithmic bytes by tools/pmc_gemm_shapes.py -> gpurun_out/<tag>_gemm_traffic_by_shape.{txt,json}
 set -e
 tag=$1
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-SHAPES="nt:50432:2304:768 nt:50432:3072:768:gelu nt:50432:768:768:res:f32 nt:50432:768:3072:res:f32 \
+SHAPES="nt:50432:2304:768 nt:50432:3072:768:gelu nt:50432:768:768:res:bf16 nt:50432:768:3072:res:bf16 \
 nn:50432:3072:768:dgelu nn:50432:768:3072 nn:50432:768:2304 nn:50432:768:768 \
 tn:768:768:50432:store:f32 tn:3072:768:50432:store:f32 tn:768:3072:50432:store:f32 tn:2304:768:50432:store:f32"
 cd /tmp && export TMPDIR=/tmp
