@@ -761,3 +761,48 @@ def test_gemm_persistent_walk_covers_many_tiles_per_workgroup(ops, lib, layout, 
         outs.append([t.float().cpu() for t in res])
     for x, y in zip(outs[0], outs[1]):
         assert torch.equal(x, y), "persistent and one-tile-per-workgroup launches must agree bit for bit"
+
+
+@pytest.mark.parametrize("layout", ["nt", "nn"])
+def test_gemm_tile_order_and_store_policy_do_not_change_results(ops, lib, layout):
+    """Column-band tile orders (vitmi_debug_gemm_band: row-major, bands of 2, ragged bands of 5 over 13
+    column tiles, with and without the split tail) and the cache policies of the output stores
+    (plain / sc1 / nt) only change WHERE and HOW a tile is written: every combination must give the
+    same bits, and cover every tile (the output starts as NaN)."""
+    import ctypes
+    from vit_torch_amd import _lib as L
+    from vit_torch_amd._lib import EPI_BIAS_GELU, GEMM_FAST
+    raw = ctypes.CDLL(str(L.LIB_PATH))
+    M, N, K = 256 * 70, 256 * 13, 256
+    bt = torch.bfloat16
+    g = torch.Generator("cpu").manual_seed(91)
+    a = bf16_round(torch.randn(M, K, generator=g))
+    b = bf16_round(torch.randn(N, K, generator=g) * 0.05)
+    A = dev(a, bt)
+    bkm = layout == "nt"
+    B = dev(b if bkm else b.t().contiguous(), bt)
+    bias = dev(torch.randn(N, generator=g))
+    ref = None
+    try:
+        for band, pol in [(0, 0), (2, 0), (5, 0), (5, 1), (5, 2), (-1, -1)]:
+            raw.vitmi_debug_gemm_band(band)
+            raw.vitmi_debug_gemm_store_policy(pol)
+            C = torch.full((M, N), float("nan"), device="cuda").to(bt)
+            if layout == "nt":
+                P = torch.full((M, N), float("nan"), device="cuda").to(bt)
+                ops.gemm(A, B, C, epilogue=EPI_BIAS_GELU, bias=bias, C2=P, impl=GEMM_FAST)
+                out = (C.float().cpu(), P.float().cpu())
+            else:
+                ops.gemm(A, B, C, b_kmajor=False, impl=GEMM_FAST)
+                out = (C.float().cpu(),)
+            assert all(torch.isfinite(t).all() for t in out), (band, pol)
+            if ref is None:
+                ref = out
+                want = a @ b.t()
+                assert_close("band0", out[0], F.gelu(bf16_round(want + bias.cpu())) if layout == "nt" else want, TOL[bt])
+            else:
+                for x, y in zip(out, ref):
+                    assert torch.equal(x, y), (band, pol)
+    finally:
+        raw.vitmi_debug_gemm_band(-1)
+        raw.vitmi_debug_gemm_store_policy(-1)

@@ -57,12 +57,19 @@ if __name__ == "__main__":
     specs = [a for a in specs if not a.startswith("tile=")]
     persists = [int(a[8:]) for a in specs if a.startswith("persist=")] or [1]
     specs = [a for a in specs if not a.startswith("persist=")]
+    bands = [int(a[5:]) for a in specs if a.startswith("band=")] or [-1]
+    specs = [a for a in specs if not a.startswith("band=")]
+    pols = [int(a[4:]) for a in specs if a.startswith("pol=")] or [0]
+    specs = [a for a in specs if not a.startswith("pol=")]
     pipes = [int(a[5:]) for a in sys.argv[1:] if a.startswith("pipe=")] or [-1]
     tiles = [int(a[5:]) for a in sys.argv[1:] if a.startswith("tile=")] or [-1]
-    for tm, pm, ps in [(t, p, q) for t in tiles for p in pipes for q in persists]:
+    for tm, pm, ps, bd, pol in [(t, p, q, b, c) for t in tiles for p in pipes for q in persists for b in bands for c in pols]:
+        raw.vitmi_debug_gemm_store_policy(pol)
+        print(f"--- store policy {pol}")
         raw.vitmi_debug_gemm_tile(tm)
         raw.vitmi_debug_gemm_pipe(pm)
         raw.vitmi_debug_gemm_persist(ps)
-        print(f"--- tile {tm} pipe {pm} persistent {ps}")
+        raw.vitmi_debug_gemm_band(bd)
+        print(f"--- tile {tm} pipe {pm} persistent {ps} band {bd}")
         for s in (specs or DEFAULT):
             run(s)

@@ -17,6 +17,7 @@ struct EpiArgs {
   const float* rowscale; int64_t rpg;      // RESIDUAL: per-row-group branch scale (DropPath)
   float* colsum_part;                      // DGELU, fast path: [M/128][N] column sums of C
   int aux_deriv;                           // GELU: C2 = gelu'(pre) instead of pre; DGELU: C = acc * AUX
+  int c_policy;                            // tile kernels: cache policy of the C / C2 stores (0 plain, 1 sc1, 2 nt)
 };
 
 struct GemmArgs {
@@ -29,6 +30,7 @@ struct GemmArgs {
   int64_t batch, batch_inner, a_bs[2], b_bs[2], c_bs[2];   // batched form (generic kernel)
   int vec_a, vec_b;               // operand rows are 16-B aligned: vector staging allowed
   int rfold;                      // gemm_fast: stream the fp32 residual through LDS during the main loop
+  int band;                       // gemm_fast: column-band width of the tile order (0 = row-major)
   EpiArgs e;
 };
 

@@ -142,6 +142,18 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs g) {
 
 }  // namespace
 
+// Cache policy of the tile kernels' output stores (storev_pol): -1 = automatic, else forced (diagnostic hook).
+// Automatic: `nt` for the wide activation outputs that are written once and read by a LATER kernel
+// (qkv, fc1's two outputs, the data gradients: >= 64 MB), plain for everything else (the residual
+// stream's new rows are read back at once by the LayerNorm that follows, weight-gradient tiles are small).
+static int g_c_policy = -1;
+extern "C" void vitmi_debug_gemm_store_policy(int p) { g_c_policy = p; }
+static int store_policy(const vitmi_gemm_desc* d) {
+  if (g_c_policy >= 0) return g_c_policy;
+  if (d->epilogue == VITMI_EPI_RESIDUAL || d->epilogue == VITMI_EPI_PATCH_POS) return 0;
+  const int64_t bytes = d->M * d->N * (d->c_dtype == VITMI_BF16 ? 2 : 4);
+  return bytes >= (64ll << 20) ? 2 : 0;
+}
 static int build_args(const vitmi_gemm_desc* d, GemmArgs* out) {
   VITMI_REQUIRE(d, VITMI_E_BADARG, "gemm: null descriptor");
   VITMI_REQUIRE(d->struct_size == (int64_t)sizeof(vitmi_gemm_desc), VITMI_E_BADARG,
@@ -162,6 +174,7 @@ static int build_args(const vitmi_gemm_desc* d, GemmArgs* out) {
   g.B = d->B; g.ldb = d->ldb; g.b_km = d->b_kmajor ? 1 : 0;
   g.ws = d->workspace; g.ws_bytes = d->workspace_bytes;
   g.rfold = 0;
+  g.band = 0;
   g.dbg = g_gemm_dbg;
   g.dbg_blocks = g_gemm_dbg_blocks;
   g.batch = d->batch > 1 ? d->batch : 1;
@@ -189,6 +202,7 @@ static int build_args(const vitmi_gemm_desc* d, GemmArgs* out) {
   e.gamma = d->gamma;
   e.AUX = d->AUX; e.ldaux = d->ldaux; e.aux_bf16 = d->in_dtype == VITMI_BF16;
   e.aux_deriv = d->aux_is_derivative != 0;
+  e.c_policy = store_policy(d);
   e.pos = d->pos; e.n_tok = d->n_tok; e.ldpos = d->N; e.cls = d->cls;
   e.alpha = d->alpha == 0.f ? 1.f : d->alpha;
   e.accumulate = d->accumulate;

@@ -287,6 +287,21 @@ __device__ __forceinline__ float* strip_at(float* tr, int row, int col) {
   return tr + row * 64 + ((((col >> 2) ^ row) & 15) << 2);
 }
 
+// Linear tile index -> (row tile, column tile).  band == 0: row-major over all column tiles.  band > 0:
+// column BANDS of `band` tiles, row-major inside a band, bands one after the other (the last may be
+// narrower).  An XCD's contiguous run of the order is then (rows x band) instead of (few rows x all
+// columns): the band's B panels (band x 256 x K x 2 B) stay in its 4-MiB L2 from round to round while
+// the A panels stream, where the row-major order re-fetches a whole N x K weight matrix that does
+// not fit (N = 3072, K = 768: 4.7 MB) every round.
+__device__ __forceinline__ void tile_mn(int t, int tiles_m, int tiles_n, int band, int* mt, int* nt) {
+  if (band <= 0 || band >= tiles_n) { *mt = t / tiles_n; *nt = t % tiles_n; return; }
+  const int per_band = tiles_m * band;
+  const int b = t / per_band, r = t - b * per_band;
+  const int w = min(band, tiles_n - b * band);
+  *mt = r / w;
+  *nt = b * band + r % w;
+}
+
 // PERSISTENT tile walk (every launch but split-K): the grid is min(tiles, CUs) workgroups, one per
 // CU (a workgroup takes the CU's whole register file and >= 128 KiB of LDS), and each walks the
 // tiles slot, slot + G/8, ... of its XCD's contiguous run (the same tile -> XCD order as before).
@@ -398,7 +413,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
   int idx = slot;                                  // position inside the XCD's run (PERSIST)
   int tile = tile0 + (SPLITK ? wg0 % ntiles : x_start + idx);
   if (PERSIST && idx >= x_len) return;
-  int64_t m0 = (int64_t)(tile / tiles_n) * BM, n0 = (int64_t)(tile % tiles_n) * BN;
+  const int tiles_m = (int)(g.M / BM);
+  int mt_, nt_;
+  tile_mn(tile, tiles_m, tiles_n, g.band, &mt_, &nt_);
+  int64_t m0 = (int64_t)mt_ * BM, n0 = (int64_t)nt_ * BN;
   start_tile(m0, n0);
   bool prefetched = false;                         // the tile's prologue DMAs were issued before an epilogue
 
@@ -625,8 +643,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
       // put the whole prefetch in front of the epilogue
       __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): nothing but these two small loads is outstanding
       const int tn = x_start + nidx;
-      m0n = (int64_t)(tn / tiles_n) * BM;
-      n0n = (int64_t)(tn % tiles_n) * BN;
+      tile_mn(tn, tiles_m, tiles_n, g.band, &mt_, &nt_);
+      m0n = (int64_t)mt_ * BM;
+      n0n = (int64_t)nt_ * BN;
       start_tile(m0n, n0n);
     }
   }
@@ -704,8 +723,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
     idx += gx;
     if (idx >= x_len) break;
     tile = x_start + idx;
-    m0 = (int64_t)(tile / tiles_n) * BM;
-    n0 = (int64_t)(tile % tiles_n) * BN;
+    tile_mn(tile, tiles_m, tiles_n, g.band, &mt_, &nt_);
+    m0 = (int64_t)mt_ * BM;
+    n0 = (int64_t)nt_ * BN;
     __syncthreads();                               // the strips of PIPE 0 sit above the stages too; stages reused at once
   } else {
     if (!has_next) break;
@@ -755,13 +775,15 @@ inline void splitk_plan(int tiles, int nt, int* splits, int* ksps) {
 // block b of a tile covers rows 16b..16b+15, a thread W columns of one row (full lines).
 template <int MODE, typename TC>
 __global__ __launch_bounds__(256) void tail_epilogue_kernel(const float* __restrict__ ws, int splits, EpiArgs e,
-                                                           int64_t M, int64_t N, int tiles_n, int tile0) {
+                                                           int64_t M, int64_t N, int tiles_n, int tile0, int band) {
   constexpr int W = sizeof(TC) == 2 ? 8 : 4;
   constexpr int TPR = 256 / W;                       // threads per 256-column row
   constexpr int RPB = 256 / TPR;                     // rows per pass of the block
   const int tile = tile0 + blockIdx.x / 16;
-  const int64_t m0 = (int64_t)(tile / tiles_n) * BM + (blockIdx.x % 16) * 16;
-  const int64_t n = (int64_t)(tile % tiles_n) * BN + (threadIdx.x % TPR) * W;
+  int mt_, nt_;
+  tile_mn(tile, (int)(M / BM), tiles_n, band, &mt_, &nt_);
+  const int64_t m0 = (int64_t)mt_ * BM + (blockIdx.x % 16) * 16;
+  const int64_t n = (int64_t)nt_ * BN + (threadIdx.x % TPR) * W;
   float b[W], gm[W];
 #pragma unroll
   for (int i = 0; i < W; ++i) { b[i] = 0.f; gm[i] = 1.f; }
@@ -864,12 +886,34 @@ static int persistent_grid(int nwg) {
   return nwg < cus ? nwg : cus;
 }
 
+// Column-band width of the tile order (tile_mn): bands only where the whole B matrix does not fit an
+// XCD's L2 beside the streaming operands (N x K x 2 B > 3 MiB) and there are rows enough to fill the
+// XCDs inside a band; the band is the widest divisor-free choice whose B panels take <= 2 MiB.
+static int g_band_override = -1;     // diagnostic hook: -1 = automatic, 0 = row-major, n = bands of n column tiles
+extern "C" void vitmi_debug_gemm_band(int n) { g_band_override = n; }
+static int band_for(const GemmArgs& g, int tiles_m, int tiles_n) {
+  if (g_band_override >= 0) return g_band_override;
+  const int64_t b_bytes = g.N * g.K * 2;
+  if (b_bytes <= (3 << 20) || tiles_n < 2 || tiles_m < 64) return 0;
+  const int64_t panel = (int64_t)BN * g.K * 2;
+  int band = (int)((2 << 20) / panel);
+  if (band < 1) band = 1;
+  if (band >= tiles_n) return 0;
+  for (int d = band; 2 * d >= band && d >= 1; --d)      // a divisor of tiles_n close below, if there is one
+    if (tiles_n % d == 0) { band = d; break; }
+  // distinct operand panels an XCD's round of 32 tiles pulls from beyond L2: 32/band rows of A with
+  // the band's B resident, against 32/tiles_n rows + all tiles_n columns in row-major order
+  if (32.0 / band >= 32.0 / tiles_n + tiles_n) return 0;
+  return band;
+}
+
 template <bool A_KM, bool B_KM, int MODE, typename TC, int PIPE>
 int launch_p(const GemmArgs& g_in, hipStream_t stream) {
   GemmArgs g = g_in;
   g.rfold = g_rfold_override == 0 ? 0 : 1;
   const int tiles_m = (int)(g.M / BM), tiles_n = (int)(g.N / BN);
   const int nwg = tiles_m * tiles_n;
+  g.band = band_for(g, tiles_m, tiles_n);
   if constexpr (MODE == VITMI_EPI_STORE && sizeof(TC) == 4) {
     int splits, ksps;
     splitk_plan(nwg, (int)(g.K / BK), &splits, &ksps);
@@ -906,7 +950,7 @@ int launch_p(const GemmArgs& g_in, hipStream_t stream) {
       if (rc) return rc;
       hipLaunchKernelGGL(ktail, dim3(rem * splits), dim3(NTHREADS), 2 * STAGE_BYTES, stream, g, tiles_n, rem * splits, rem, ksps, ws, full);
       if ((rc = vitmi_check_launch("gemm_fast_kernel(tail slices)"))) return rc;
-      hipLaunchKernelGGL((tail_epilogue_kernel<MODE, TC>), dim3(rem * 16), dim3(256), 0, stream, ws, splits, g.e, g.M, g.N, tiles_n, full);
+      hipLaunchKernelGGL((tail_epilogue_kernel<MODE, TC>), dim3(rem * 16), dim3(256), 0, stream, ws, splits, g.e, g.M, g.N, tiles_n, full, g.band);
       return vitmi_check_launch("tail_epilogue_kernel");
     }
   }

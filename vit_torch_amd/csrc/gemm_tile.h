@@ -148,6 +148,31 @@ __device__ __forceinline__ void storev(T* p, const float (&v)[W]) {
   }
 }
 
+// The same store with a cache policy for output tiles: 1 = `sc1` (the line is written through and
+// DROPPED from the XCD's L2), 2 = `nt`.  A GEMM's C / C2 tiles are never read again by the launch
+// that writes them, and left in L2 they evict the operand panels the next tiles of the XCD share.
+template <typename T, int W>
+__device__ __forceinline__ void storev_pol(T* p, const float (&v)[W], int policy) {
+  if (policy == 0) { storev<T, W>(p, v); return; }
+  if constexpr (sizeof(T) == 2 && W == 8) {
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (bf16)v[i];
+    if (policy == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(o) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(p), "v"(o) : "memory");
+  } else if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int q = 0; q < W / 4; ++q) {
+      const f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+      T* pq = p + 4 * q;
+      if (policy == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(pq), "v"(o) : "memory");
+      else asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(pq), "v"(o) : "memory");
+    }
+  } else {
+    storev<T, W>(p, v);
+  }
+}
+
 // epilogue on W consecutive columns n.. of row m; v = raw accumulators in, stored out
 // b / gm: bias and LayerScale of the lane's W columns (the same for every row, so the
 // caller loads them ONCE: a load inside the row loop would put a vmcnt wait, which also
@@ -213,13 +238,13 @@ __device__ __forceinline__ void epi_row(const EpiArgs& e, int64_t mu, int64_t ml
         v[i] = r[0]; v[i + 1] = r[1];
       }
     }
-    if (e.C2) storev<TC, W>(reinterpret_cast<TC*>(e.C2) + row_off(mu, ml, e.ldc2, n), pre);
+    if (e.C2) storev_pol<TC, W>(reinterpret_cast<TC*>(e.C2) + row_off(mu, ml, e.ldc2, n), pre, e.c_policy);
   } else if constexpr (MODE == VITMI_EPI_RESIDUAL) {
     if (e.C2) {                              // un-scaled branch output, operand dtype (bf16 here)
       float f[W];
 #pragma unroll
       for (int i = 0; i < W; ++i) f[i] = v[i] + b[i];
-      storev<bf16, W>(reinterpret_cast<bf16*>(e.C2) + row_off(mu, ml, e.ldc2, n), f);
+      storev_pol<bf16, W>(reinterpret_cast<bf16*>(e.C2) + row_off(mu, ml, e.ldc2, n), f, e.c_policy);
     }
     float rs = 1.f;
     if (e.rowscale) rs = e.rowscale[(uint32_t)m / (uint32_t)e.rpg];      // uniform branch; M < 2^32
@@ -250,7 +275,7 @@ __device__ __forceinline__ void epi_row(const EpiArgs& e, int64_t mu, int64_t ml
       for (int i = 0; i < W; ++i) v[i] = v[i] + b[i] + ps[i];
     }
   }
-  storev<TC, W>(C + row_off(mu, ml, e.ldc, n), v);
+  storev_pol<TC, W>(C + row_off(mu, ml, e.ldc, n), v, e.c_policy);
 }
 template <int MODE, typename TC, int W>
 __device__ __forceinline__ void epi_row(const EpiArgs& e, int64_t m, int64_t n, float (&v)[W],
