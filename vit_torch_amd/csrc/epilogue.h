@@ -17,6 +17,7 @@ struct EpiArgs {
   const float* rowscale; int64_t rpg;      // RESIDUAL: per-row-group branch scale (DropPath)
   float* colsum_part;                      // DGELU, fast path: [M/128][N] column sums of C
   int aux_deriv;                           // GELU: C2 = gelu'(pre) instead of pre; DGELU: C = acc * AUX
+  int side_nt;                             // tile kernels: non-temporal loads of R / AUX
   int c_policy;                            // tile kernels: cache policy of the C / C2 stores (0 plain, 1 sc1, 2 nt)
 };
 

@@ -148,6 +148,12 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs g) {
 // stream's new rows are read back at once by the LayerNorm that follows, weight-gradient tiles are small).
 static int g_c_policy = -1;
 extern "C" void vitmi_debug_gemm_store_policy(int p) { g_c_policy = p; }
+static int g_side_nt = -1;           // diagnostic hook: -1 = automatic (wide side inputs), 0 / 1 forced
+extern "C" void vitmi_debug_gemm_side_nt(int v) { g_side_nt = v; }
+static int side_policy(const vitmi_gemm_desc* d) {
+  if (g_side_nt >= 0) return g_side_nt;
+  return d->M * d->N * 2 >= (64ll << 20) ? 1 : 0;
+}
 static int store_policy(const vitmi_gemm_desc* d) {
   if (g_c_policy >= 0) return g_c_policy;
   if (d->epilogue == VITMI_EPI_RESIDUAL || d->epilogue == VITMI_EPI_PATCH_POS) return 0;
@@ -203,6 +209,7 @@ static int build_args(const vitmi_gemm_desc* d, GemmArgs* out) {
   e.AUX = d->AUX; e.ldaux = d->ldaux; e.aux_bf16 = d->in_dtype == VITMI_BF16;
   e.aux_deriv = d->aux_is_derivative != 0;
   e.c_policy = store_policy(d);
+  e.side_nt = side_policy(d);
   e.pos = d->pos; e.n_tok = d->n_tok; e.ldpos = d->N; e.cls = d->cls;
   e.alpha = d->alpha == 0.f ? 1.f : d->alpha;
   e.accumulate = d->accumulate;

@@ -148,6 +148,26 @@ __device__ __forceinline__ void storev(T* p, const float (&v)[W]) {
   }
 }
 
+// Side inputs of an epilogue (residual rows, saved GELU derivative) are read exactly once: the
+// non-temporal form keeps them from taking L2 lines the operand panels would re-use.
+template <typename T, int W>
+__device__ __forceinline__ void loadv_nt(const T* p, float (&o)[W]) {
+  if constexpr (sizeof(T) == 2 && W == 8) {
+    const bf16x8 v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+  } else if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int q = 0; q < W / 4; ++q) {
+      const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 4 * q));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[4 * q + i] = v[i];
+    }
+  } else {
+    loadv<T, W>(p, o);
+  }
+}
+
 // The same store with a cache policy for output tiles: 1 = `sc1` (the line is written through and
 // DROPPED from the XCD's L2), 2 = `nt`.  A GEMM's C / C2 tiles are never read again by the launch
 // that writes them, and left in L2 they evict the operand panels the next tiles of the XCD share.
@@ -195,8 +215,13 @@ __device__ __forceinline__ int64_t row_off(int64_t mu, int64_t ml, int64_t ld, i
 }
 template <int MODE, typename TC, int W>
 __device__ __forceinline__ void epi_side(const EpiArgs& e, int64_t mu, int64_t ml, int64_t n, float (&x)[W]) {
-  if constexpr (MODE == VITMI_EPI_RESIDUAL) loadv<TC, W>(reinterpret_cast<const TC*>(e.R) + row_off(mu, ml, e.ldr, n), x);
-  else if constexpr (MODE == VITMI_EPI_DGELU) loadv<bf16, W>(reinterpret_cast<const bf16*>(e.AUX) + row_off(mu, ml, e.ldaux, n), x);
+  if constexpr (MODE == VITMI_EPI_RESIDUAL) {
+    if (e.side_nt) loadv_nt<TC, W>(reinterpret_cast<const TC*>(e.R) + row_off(mu, ml, e.ldr, n), x);
+    else loadv<TC, W>(reinterpret_cast<const TC*>(e.R) + row_off(mu, ml, e.ldr, n), x);
+  } else if constexpr (MODE == VITMI_EPI_DGELU) {
+    if (e.side_nt) loadv_nt<bf16, W>(reinterpret_cast<const bf16*>(e.AUX) + row_off(mu, ml, e.ldaux, n), x);
+    else loadv<bf16, W>(reinterpret_cast<const bf16*>(e.AUX) + row_off(mu, ml, e.ldaux, n), x);
+  }
   else if constexpr (MODE == VITMI_EPI_STORE && sizeof(TC) == 4) loadv<float, W>(reinterpret_cast<const float*>(e.C) + row_off(mu, ml, e.ldc, n), x);
 }
 template <int MODE, typename TC, int W>
