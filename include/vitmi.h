@@ -47,6 +47,12 @@ enum {
 
 int vitmi_version(void);
 const char* vitmi_last_error_string(void);
+/* Persistent grids: by default the GEMM and attention-backward kernels launch one workgroup per CU
+ * that walks a fixed list of tiles / (image, head) pairs.  A process that runs other kernels BESIDE
+ * them on the same device (RCCL collectives overlapping the backward pass) must switch them off
+ * (on = 0: one tile / pair per workgroup, placed by the hardware dispatcher on whatever CUs are
+ * free); vit_torch_amd.ddp.GradReducer does.  Process-wide, takes effect at the next launch. */
+void vitmi_set_persistent_grids(int on);
 
 /* ---------------------------------------------------------------- GEMM ---
  * C[M,N] = epilogue( sum_k A(m,k) * B(n,k) ), fp32 accumulation.

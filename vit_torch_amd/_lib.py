@@ -50,6 +50,7 @@ class GemmDesc(C.Structure):
 SIGNATURES = {
     "vitmi_version": (C.c_int, []),
     "vitmi_last_error_string": (C.c_char_p, []),
+    "vitmi_set_persistent_grids": (None, [C.c_int]),
     "vitmi_gemm": (C.c_int, [C.POINTER(GemmDesc), c_vp]),
     "vitmi_gemm_uses_fast": (C.c_int, [C.POINTER(GemmDesc)]),
     "vitmi_gemm_workspace": (c_sz, [C.POINTER(GemmDesc)]),

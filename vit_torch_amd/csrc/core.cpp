@@ -52,7 +52,8 @@ int vitmi_cu_count() {
 }
 
 static std::atomic<int> g_persist{1};
-extern "C" void vitmi_debug_gemm_persist(int on) { g_persist.store(on, std::memory_order_relaxed); }
+extern "C" void vitmi_set_persistent_grids(int on) { g_persist.store(on != 0, std::memory_order_relaxed); }
+extern "C" void vitmi_debug_gemm_persist(int on) { vitmi_set_persistent_grids(on); }   // name the tools use
 int vitmi_persist_on() { return g_persist.load(std::memory_order_relaxed); }
 
 int vitmi_raise_dynamic_lds(const void* kern, int bytes, const char* who) {

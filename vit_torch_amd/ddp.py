@@ -31,11 +31,11 @@ class GradReducer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         if self.world > 1 or self.force:
             # RCCL's all-reduce kernels hold a few dozen CUs while a bucket is in flight, and a 256x256-tile
-            # GEMM workgroup needs a whole CU: with the persistent grid (a FIXED tile list per workgroup)
+            # GEMM / attention-backward workgroup needs a whole CU: with the persistent grids (a FIXED tile list per workgroup)
             # the workgroups that find their CU taken would start only when another one has walked
             # its whole list.  One tile per workgroup lets the dispatcher balance over the free CUs.
             from ._lib import load
-            load().vitmi_debug_gemm_persist(0)
+            load().vitmi_set_persistent_grids(0)
         self.min_bucket = int(min_bucket_elems)
         self._pending_lo: Optional[int] = None
         self._pending_hi: Optional[int] = None
