@@ -852,3 +852,40 @@ def test_gemm_row_split_tail(ops, lib):
     rows_full = 256 // 4 * 256
     for x, y in zip(res[0][:5], res[1][:5]):
         assert torch.equal(x[:rows_full], y[:rows_full])
+
+
+def test_attention_bwd_persistent_pair_walk(ops, lib):
+    """More (image, head) pairs than CUs: the fused backward's workgroups walk several pairs each,
+    loading the next pair while the current one is written out (276 pairs on 256 CUs: 20 workgroups
+    take two).  Must equal the one-pair-per-workgroup launch bit for bit, bias partials included,
+    and autograd within the bf16 tolerance."""
+    import ctypes
+    from vit_torch_amd import _lib as L
+    raw = ctypes.CDLL(str(L.LIB_PATH))
+    B, N, H, hd = 23, 197, 12, 64
+    bt = torch.bfloat16
+    scale = hd ** -0.5
+    qkv = bf16_round(gen((B, N, 3 * H * hd), 21))
+    do = bf16_round(gen((B, N, H * hd), 22))
+    QKV, DO = dev(qkv, bt), dev(do, bt)
+    O = torch.empty((B, N, H * hd), device="cuda", dtype=bt)
+    lse = torch.empty(B * H * N, device="cuda")
+    ops.attn_fwd(QKV, O, lse, B, N, H, hd, scale)
+    outs = []
+    try:
+        for persist in (1, 0):
+            lib.vitmi_set_persistent_grids(persist)
+            dqkv = torch.full((B, N, 3 * H * hd), float("nan"), device="cuda").to(bt)
+            part = torch.full((ops.attn_bwd_dbias_rows(B, N), 3 * H * hd), float("nan"), device="cuda")
+            ops.attn_bwd(QKV, O, DO, lse, dqkv, B, N, H, hd, scale, dbias_part=part)
+            outs.append((dqkv.float().cpu(), part.cpu()))
+            assert torch.isfinite(outs[-1][0]).all() and torch.isfinite(outs[-1][1]).all()
+    finally:
+        lib.vitmi_set_persistent_grids(1)
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+    qr = qkv.clone().requires_grad_(True)
+    o_ref, _ = attn_ref(qr, B, N, H, hd, scale)
+    o_ref.backward(do)
+    assert_close("dqkv", outs[0][0], qr.grad, 2.5e-2)
+    assert_close("dbias", outs[0][1].sum(0), qr.grad.view(B * N, -1).sum(0), 2.5e-2)
