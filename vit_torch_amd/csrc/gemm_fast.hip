@@ -860,6 +860,10 @@ int launch(const GemmArgs& g, hipStream_t stream) {
   constexpr bool CAN_FOLD = MODE == VITMI_EPI_RESIDUAL && sizeof(TC) == 4;
   if (pm < 0) {
     pm = (A_KM && B_KM) ? 2 : 1;   // k-major operands want full-line DMA (PIPE 2)
+    // the plain-store forward with a short contraction (qkv: K = 768) runs best on the simple two-stage
+    // loop: 189 -> 175 us inside the ViT-B/16 step (A/B of the three loops in one process); with an
+    // epilogue that reads or computes (GELU, residual) or K = 3072 the phased loops win
+    if (A_KM && B_KM && MODE == VITMI_EPI_STORE && sizeof(TC) == 2 && g.K <= 1024) pm = 0;
     // the fp32-stream residual epilogue takes the ring-of-three loop that streams R through LDS
     if (CAN_FOLD && g_rfold_override != 0 && !g.e.gamma && !g.e.rowscale && !g.e.C2 && !g.e.r_bf16 && g.K >= 640) pm = 3;
   }
