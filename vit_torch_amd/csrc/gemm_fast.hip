@@ -407,6 +407,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
         ta.issue(smem + STAGE_BYTES, 1, wave);
         tb.issue(smem + STAGE_BYTES + TILE_BYTES, 1, wave);
       }
+    } else {                       // PIPE 0: stage 0 (the loop issues stage t + 1 itself)
+      stage_tile<A_KM>(smem, A, g.lda, m0, kb0, wave, lane);
+      stage_tile<B_KM>(smem + TILE_BYTES, B, g.ldb, n0, kb0, wave, lane);
     }
   };
 
@@ -429,9 +432,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
     for (int mi = 0; mi < 8; ++mi) { acc[ni][mi][0] = 0.f; acc[ni][mi][1] = 0.f; acc[ni][mi][2] = 0.f; acc[ni][mi][3] = 0.f; }
 
   if constexpr (PIPE == 0) {
-  stage_tile<A_KM>(smem, A, g.lda, m0, kb0, wave, lane);
-  stage_tile<B_KM>(smem + TILE_BYTES, B, g.ldb, n0, kb0, wave, lane);
-  __syncthreads();
+  __syncthreads();                 // stage 0 (start_tile) has landed: vmcnt(0) + barrier
 
   for (int t = 0; t < nt; ++t) {
     char* cur = smem + (t & 1) * STAGE_BYTES;
@@ -634,7 +635,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
   // ---- the next tile of this workgroup: its first stages start to fill now
   bool has_next = false;
   int64_t m0n = 0, n0n = 0;
-  if constexpr (PERSIST && PIPE != 0) {
+  if constexpr (PERSIST) {
     const int nidx = idx + gx;
     has_next = nidx < x_len;
     if (has_next) {
@@ -719,15 +720,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
   }
   // ---- next tile
   if constexpr (!PERSIST) break;
-  else if constexpr (PIPE == 0) {
-    idx += gx;
-    if (idx >= x_len) break;
-    tile = x_start + idx;
-    tile_mn(tile, tiles_m, tiles_n, g.band, &mt_, &nt_);
-    m0 = (int64_t)mt_ * BM;
-    n0 = (int64_t)nt_ * BN;
-    __syncthreads();                               // the strips of PIPE 0 sit above the stages too; stages reused at once
-  } else {
+  else {
     if (!has_next) break;
     idx += gx;
     m0 = m0n;
