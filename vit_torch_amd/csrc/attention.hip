@@ -680,22 +680,25 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
 
 
 // ------------------------------------- backward, whole sequence in one CU ---
-// For N <= 256 one workgroup holds Q, dO and the fp32 dQ of a whole (image, head) in LDS
-// and wave w owns key block w (K and V rows in registers): FIVE products per
+// For N <= 256 one workgroup holds Q, dO and K of a whole (image, head) in LDS and wave w owns
+// key block w (K and V fragments in registers) AND query block w's dQ: FIVE products per
 // (query block, key block) pair instead of the seven of the dkdv + dq pair, one exp per
 // score instead of two, no delta kernel (rowsum(dO*O) is taken while dO is staged).
 //   S = Q K^T, dP = dO V^T           key on the lane (as in dkdv)
 //   dV^T += dO^T P, dK^T += Q^T dS   accumulators stay in registers (own keys)
-//   dQ^T(j) += K^T dS^T              dS goes through a wave-private 2-KiB LDS tile
-//                                    [key][q] and comes back transposed (ds_read_b64_tr_b16)
-// dQ of query block j is summed over the waves: at step t wave w works on query block
-// (w + t) mod nw, so no two waves touch the same dQ block in a step and a plain LDS
-// read-modify-write between two barriers is exact and in a fixed order (deterministic).
+//   dQ^T(w) += K(w')^T dS(w, w')^T   accumulators stay in registers (own queries)
+// At step t wave w computes the pair (query block (w + t) mod nw, key block w) and leaves dS in its
+// LDS tile [key][q]; after the step's barrier the OWNER of that query block — wave (w + t) mod nw —
+// reads the tile back transposed (ds_read_b64_tr_b16) together with K^T fragments of key block w
+// from the K image and adds the product to its dQ accumulators.  Seen from wave w: its source at
+// step t is wave (w - t) mod nw.  The tiles are double buffered (a tile of step t is read while
+// step t + 1's is written), so one barrier per step orders everything; every sum has a fixed
+// order (deterministic).  (Round 1-2a kept an fp32 dQ image in LDS instead and read-modify-wrote
+// it every step: 16 of the 36 KB of LDS traffic per wave and step, and 61 of 145 KB of LDS.)
 template <int HD> struct FusedBwdCfg {
   static constexpr int QS = AttnCfg<HD>::KS;     // staged Q / dO / K row (bytes)
-  static constexpr int DQS = HD * 4 + 16;        // fp32 dQ row (bytes)
-  static constexpr int TPITCH = 80;              // dS tile row pitch (bytes): 64 B of keys + pad against bank conflicts
-  static constexpr int ROW_BYTES = 2 * QS + DQS + 8 + TPITCH;   // + lse, delta, dS tile share
+  static constexpr int TPITCH = 80;              // dS tile row pitch (bytes): 64 B of queries + pad against bank conflicts
+  static constexpr int ROW_BYTES = 3 * QS + 8 + 2 * TPITCH;   // + lse, delta, two dS tile shares
 };
 
 template <int HD, bool DBIAS>
@@ -709,7 +712,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16* __restr
                                                              unsigned long long* dbg) {
   using C = AttnCfg<HD>;
   using F = FusedBwdCfg<HD>;
-  constexpr int QS = F::QS, DQS = F::DQS, CPR = HD / 8;
+  constexpr int QS = F::QS, CPR = HD / 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
@@ -717,11 +720,10 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16* __restr
   const int NP = nw * 32;
   char* Ql = smem;
   char* dOl = Ql + NP * QS;
-  char* dQl = dOl + NP * QS;                       // first the K staging, then fp32 dQ
-  float* lse_s = reinterpret_cast<float*>(dQl + NP * DQS);
+  char* Kl = dOl + NP * QS;
+  float* lse_s = reinterpret_cast<float*>(Kl + NP * QS);
   float* del_s = lse_s + NP;
-  char* Tbase = reinterpret_cast<char*>(del_s + NP);
-  char* Tl = Tbase + w * 32 * F::TPITCH;
+  char* Tbase = reinterpret_cast<char*>(del_s + NP);              // [2][nw] dS tiles of 32 x TPITCH bytes
   const int64_t ts = (int64_t)3 * H * HD;
   const int64_t os = (int64_t)H * HD;
   const int key = w * 32 + lr;
@@ -807,7 +809,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16* __restr
     }
     *reinterpret_cast<bf16x8*>(Ql + row * QS + pc * 16) = q8[i];
     *reinterpret_cast<bf16x8*>(dOl + row * QS + pc * 16) = d8[i];
-    *reinterpret_cast<bf16x8*>(dQl + row * QS + pc * 16) = k8[i];
+    *reinterpret_cast<bf16x8*>(Kl + row * QS + pc * 16) = k8[i];
     float dot = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) dot = fmaf((float)d8[i][e], (float)o8[i][e], dot);
@@ -831,30 +833,20 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16* __restr
   bf16x8 kf[C::KSTEPS];                            // B[k = d][n = key] of S = Q K^T
 #pragma unroll
   for (int s = 0; s < C::KSTEPS; ++s)
-    kf[s] = *reinterpret_cast<const bf16x8*>(dQl + key * QS + (16 * s + 8 * h5) * 2);
-  bf16x8 kT[2][C::DB];                             // A[m = d][k = key] of dQ^T += K^T dS^T
-#pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-    for (int db = 0; db < C::DB; ++db) kT[s2][db] = load_tr_frag(dQl, QS, w * 32 + 16 * s2, db * 32, lane);
-  __syncthreads();                                 // K staging consumed: the region becomes dQ
-  {
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    for (int c = tid; c < NP * DQS / 16; c += nthr) *reinterpret_cast<f32x4*>(dQl + c * 16) = z;
-  }
-  __syncthreads();
+    kf[s] = *reinterpret_cast<const bf16x8*>(Kl + key * QS + (16 * s + 8 * h5) * 2);
 
-  f32x16 dk[C::DB], dv[C::DB];
+  f32x16 dk[C::DB], dv[C::DB], dq[C::DB];          // own keys; own queries (rows d, lane = key / query)
 #pragma unroll
-  for (int db = 0; db < C::DB; ++db) { zero16(dk[db]); zero16(dv[db]); }
+  for (int db = 0; db < C::DB; ++db) { zero16(dk[db]); zero16(dv[db]); zero16(dq[db]); }
   if (dbg_on) tl[2] = attn_stamp();
 
 #pragma unroll 1
   for (int t = 0; t < nw; ++t) {
     int j = w + t;
     if (j >= nw) j -= nw;
+    char* Tw = Tbase + ((t & 1) * nw + w) * 32 * F::TPITCH;      // this step's dS tile of this wave
     // Every LDS read of the step that does not depend on this step's dS is issued up
-    // front: the compiler cannot move a read of Ql / dOl / dQl above the T-tile stores
+    // front: the compiler cannot move a read of Ql / dOl above the T-tile stores
     // (may alias), and would otherwise pay one LDS round trip per product.
     bf16x8 aq[C::KSTEPS], ado[C::KSTEPS];
 #pragma unroll
@@ -875,15 +867,6 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16* __restr
       for (int db = 0; db < C::DB; ++db) {
         doT[s2][db] = load_tr_frag(dOl, QS, j * 32 + 16 * s2, db * 32, lane);
         qT[s2][db] = load_tr_frag(Ql, QS, j * 32 + 16 * s2, db * 32, lane);
-      }
-    char* dqrow = dQl + (j * 32 + lr) * DQS + 16 * h5;
-    f32x16 dq[C::DB];                              // accumulator rows d = db*32 + 8*g + 4*h5 + e
-#pragma unroll
-    for (int db = 0; db < C::DB; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(dqrow + (db * 32 + 8 * g) * 4);
-        dq[db][4 * g] = v[0]; dq[db][4 * g + 1] = v[1]; dq[db][4 * g + 2] = v[2]; dq[db][4 * g + 3] = v[3];
       }
     f32x16 s, dp;
     zero16(s);
@@ -916,19 +899,14 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16* __restr
         dp[r] = s[r] * (dp[r] - de[g][e]);
       }
     }
-    // dS -> wave-private tile T[key][q] (bf16), 4 consecutive queries per store
+    // dS -> this wave's tile T[key][q] (bf16), 4 consecutive queries per store
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       bf16x4 o4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o4[e] = (bf16)dp[4 * g + e];
-      *reinterpret_cast<bf16x4*>(Tl + lr * F::TPITCH + (8 * g + 4 * h5) * 2) = o4;
+      *reinterpret_cast<bf16x4*>(Tw + lr * F::TPITCH + (8 * g + 4 * h5) * 2) = o4;
     }
-    // dS^T back (same wave: DS operations execute in order); the dV / dK products cover
-    // the round trip
-    bf16x8 bT[2];
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) bT[s2] = load_tr_frag(Tl, F::TPITCH, 16 * s2, 0, lane);
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       const bf16x8 pf = pack8(s, 8 * s2);
@@ -939,29 +917,31 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16* __restr
         dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qT[s2][db], dsf, dk[db], 0, 0, 0);
       }
     }
-    // dQ^T(j)[d][q] += K^T[d][key] dS^T[key][q]
+    __syncthreads();                               // every dS tile of step t is written
+    // dQ^T(w)[d][q] += K(w')^T[d][key] dS(w, w')^T[key][q],  w' = (w - t) mod nw
+    int wsrc = w - t;
+    if (wsrc < 0) wsrc += nw;
+    const char* Ts = Tbase + ((t & 1) * nw + wsrc) * 32 * F::TPITCH;
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const bf16x8 bT = load_tr_frag(Ts, F::TPITCH, 16 * s2, 0, lane);
 #pragma unroll
-      for (int db = 0; db < C::DB; ++db)
-        dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT[s2][db], bT[s2], dq[db], 0, 0, 0);
-#pragma unroll
-    for (int db = 0; db < C::DB; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 v = {dq[db][4 * g], dq[db][4 * g + 1], dq[db][4 * g + 2], dq[db][4 * g + 3]};
-        *reinterpret_cast<f32x4*>(dqrow + (db * 32 + 8 * g) * 4) = v;
+      for (int db = 0; db < C::DB; ++db) {
+        const bf16x8 kT = load_tr_frag(Kl, QS, wsrc * 32 + 16 * s2, db * 32, lane);
+        dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT, bT, dq[db], 0, 0, 0);
       }
-    __syncthreads();                               // the dQ blocks change hands
+    }
   }
+  __syncthreads();                                 // the last step's K^T / tile reads are done: all three images are dead
 
   if (dbg_on) tl[3] = attn_stamp();
-  // dK, dV: transposed accumulators (lane = key, 4 consecutive d per register run) -> bf16
-  // rows in the dead Q / dO images, so that every global store below is a 16-B piece of a
+  // dQ, dK, dV: transposed accumulators (lane = query / key, 4 consecutive d per register run) -> bf16
+  // rows in the dead K / Q / dO images, so that every global store below is a 16-B piece of a
   // 128-B row segment (a lane-per-row store tail is issue-bound: guide, 'epilogue store tail').
   int tid_s = tid;
   asm volatile("" : "+v"(tid_s));
   const int lr_s = tid_s & 31, h5_s = (tid_s >> 5) & 1, key_s = w * 32 + lr_s;
+  store_T_tile<HD>(reinterpret_cast<bf16*>(Kl + key_s * QS), dq, scale, h5_s);
   store_T_tile<HD>(reinterpret_cast<bf16*>(Ql + key_s * QS), dk, scale, h5_s);
   store_T_tile<HD>(reinterpret_cast<bf16*>(dOl + key_s * QS), dv, 1.f, h5_s);
   float* red = reinterpret_cast<float*>(Tbase);    // the dS tiles are dead: [2][nw][HD] partial sums
@@ -974,16 +954,12 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16* __restr
   for (int c = tid_s; c < N * CPR; c += nthr) {
     const int row = c / CPR, pc = c % CPR;
     bf16* grow = dqkv + (int64_t)(b * (int64_t)N + row) * ts + h * HD + pc * 8;
-    const f32x4 a = *reinterpret_cast<const f32x4*>(dQl + row * DQS + pc * 32);
-    const f32x4 b4 = *reinterpret_cast<const f32x4*>(dQl + row * DQS + pc * 32 + 16);
-    bf16x8 o8s;
+    const bf16x8 q8s = *reinterpret_cast<const bf16x8*>(Kl + row * QS + pc * 16);
+    if constexpr (DBIAS) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float x0 = a[e] * scale, x1 = b4[e] * scale;
-      o8s[e] = (bf16)x0; o8s[4 + e] = (bf16)x1;
-      if constexpr (DBIAS) { dqsum[e] += x0; dqsum[4 + e] += x1; }
+      for (int e = 0; e < 8; ++e) dqsum[e] += (float)q8s[e];
     }
-    *reinterpret_cast<bf16x8*>(grow) = o8s;
+    *reinterpret_cast<bf16x8*>(grow) = q8s;
     *reinterpret_cast<bf16x8*>(grow + H * HD) = *reinterpret_cast<const bf16x8*>(Ql + row * QS + pc * 16);
     *reinterpret_cast<bf16x8*>(grow + 2 * H * HD) = *reinterpret_cast<const bf16x8*>(dOl + row * QS + pc * 16);
   }
