@@ -808,52 +808,6 @@ def test_gemm_tile_order_and_store_policy_do_not_change_results(ops, lib, layout
         raw.vitmi_debug_gemm_store_policy(-1)
 
 
-def test_gemm_row_split_tail(ops, lib):
-    """Row-split tail (vitmi_debug_gemm_rowsplit): the tile rows covered by the full rounds run on the
-    256x256 kernel, the remaining rows on the 256x128 kernel as a second launch.  Every epilogue form it
-    applies to must cover all rows (outputs start as NaN) and agree with the one-launch result (the two
-    kernels sum k in different block orders: compared at the bf16 / fp32 tolerances, not bitwise)."""
-    import ctypes
-    from vit_torch_amd import _lib as L
-    from vit_torch_amd._lib import EPI_BIAS_GELU, EPI_DGELU, EPI_RESIDUAL, GEMM_FAST
-    raw = ctypes.CDLL(str(L.LIB_PATH))
-    M, N, K = 256 * 70, 256 * 4, 256              # 280 tiles = 1 round + 24 on 256 CUs
-    bt = torch.bfloat16
-    g = torch.Generator("cpu").manual_seed(93)
-    a = bf16_round(torch.randn(M, K, generator=g))
-    b = bf16_round(torch.randn(N, K, generator=g) * 0.05)
-    A, B, Bt = dev(a, bt), dev(b, bt), dev(b.t().contiguous(), bt)
-    bias = dev(torch.randn(N, generator=g))
-    r = bf16_round(torch.randn(M, N, generator=g))
-    aux = bf16_round(torch.randn(M, N, generator=g))
-    acc = a @ b.t()
-    res = {}
-    try:
-        for mode in (0, 1):
-            raw.vitmi_debug_gemm_rowsplit(mode)
-            nanb = lambda: torch.full((M, N), float("nan"), device="cuda").to(bt)
-            C, H, P, X, D = nanb(), nanb(), nanb(), nanb(), nanb()
-            part = torch.full((M // 128, N), float("nan"), device="cuda")
-            ops.gemm(A, B, C, bias=bias, impl=GEMM_FAST)
-            ops.gemm(A, B, H, epilogue=EPI_BIAS_GELU, bias=bias, C2=P, impl=GEMM_FAST)
-            ops.gemm(A, B, X, epilogue=EPI_RESIDUAL, bias=bias, R=dev(r, bt), impl=GEMM_FAST)
-            ops.gemm(A, Bt, D, b_kmajor=False, epilogue=EPI_DGELU, aux=dev(aux, bt), impl=GEMM_FAST, colsum_part=part)
-            res[mode] = [t.float().cpu() for t in (C, H, P, X, D, part)]
-            assert all(torch.isfinite(t).all() for t in res[mode]), mode
-    finally:
-        raw.vitmi_debug_gemm_rowsplit(-1)
-    want = [acc + bias.cpu(), F.gelu(bf16_round(acc + bias.cpu())), acc + bias.cpu(), r + acc + bias.cpu(),
-            acc * gelu_grad(aux), (acc * gelu_grad(aux)).view(M // 128, 128, N).sum(1)]
-    for i, nm in enumerate(("store", "gelu", "pre", "residual", "dgelu", "colsum_part")):
-        tol = 2e-3 if nm == "colsum_part" else TOL[bt]
-        assert_close(f"{nm}[one launch]", res[0][i], want[i], tol)
-        assert_close(f"{nm}[row split]", res[1][i], want[i], tol)
-    # the rows of the full rounds come from the same kernel either way: identical bits
-    rows_full = 256 // 4 * 256
-    for x, y in zip(res[0][:5], res[1][:5]):
-        assert torch.equal(x[:rows_full], y[:rows_full])
-
-
 def test_attention_bwd_persistent_pair_walk(ops, lib):
     """More (image, head) pairs than CUs: the fused backward's workgroups walk several pairs each,
     loading the next pair while the current one is written out (276 pairs on 256 CUs: 20 workgroups

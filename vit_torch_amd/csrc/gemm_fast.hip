@@ -1058,56 +1058,7 @@ static int gemm_fast_launch_whole(const GemmArgs& g, hipStream_t s) {
   return vitmi_fail(VITMI_E_SHAPE, "gemm_fast: combination not built");
 }
 
-// Row-split tail: a launch of q full rounds plus a remainder of at most half a round, too short in K
-// for the k-sliced tail (tail_plan), leaves more than half of the CUs idle for a whole tile time
-// (ViT-B bs 256: 591 tiles = 2 rounds + 79, 2 364 = 9 rounds + 60).  The tile rows the full rounds
-// cover go to this kernel; the remaining rows go to the 256x128-tile kernel as a second launch:
-// twice as many, half as tall workgroups, spread over all CUs (about 0.55 of a tile time instead of 1).
-// Only for forms whose rows are independent blocks of memory (A k-major, nothing indexed by the
-// absolute row).
-// MEASURED, NOT ENABLED: inside the ViT-B/16 step it changes nothing (35.40 vs 35.35 ms; fc1 forward
-// 338 -> 365 us, proj 108 -> 109): a lone 256x128 workgroup per CU takes about as long as a 256x256
-// one (its main loop is paced by the same round trips), and the second launch adds its own ramp.
-// Kept behind the hook with its test as the record of that measurement.
-static int g_rowsplit_override = -1;
-// diagnostic / test hook: 1 = whenever the shape allows, 0 / -1 = never (default)
-extern "C" void vitmi_debug_gemm_rowsplit(int mode) { g_rowsplit_override = mode; }
-static bool rowsplit_plan(const GemmArgs& g, GemmArgs* main_part, GemmArgs* rest) {
-  if (g_rowsplit_override != 1 || !g.a_km || g.batch > 1) return false;
-  const EpiArgs& e = g.e;
-  if (e.rowscale || e.mode == VITMI_EPI_PATCH_POS || e.accumulate) return false;
-  if (e.mode == VITMI_EPI_STORE && !e.c_bf16) return false;         // fp32 stores: split-K / accumulate forms
-  const int cus = vitmi_cu_count();
-  const int64_t tiles_m = g.M / BM, tiles_n = g.N / BN, tiles = tiles_m * tiles_n;
-  const int64_t q = tiles / cus, r = tiles % cus;
-  if (q < 1 || r == 0) return false;
-  if (e.mode == VITMI_EPI_STORE || e.mode == VITMI_EPI_RESIDUAL) {
-    int rem, sp, ks;
-    if (tail_plan(g, (int)tiles, &rem, &sp, &ks)) return false;      // long contractions slice the tail in k instead
-  }
-  const int64_t rows_full = q * cus / tiles_n;                       // tile rows the full rounds cover
-  if (rows_full < 1 || rows_full >= tiles_m) return false;
-  const int64_t m1 = rows_full * BM;
-  *main_part = g;
-  main_part->M = m1;
-  *rest = g;
-  rest->M = g.M - m1;
-  rest->A = reinterpret_cast<const bf16*>(g.A) + m1 * g.lda;
-  EpiArgs& f = rest->e;
-  f.C = reinterpret_cast<char*>(e.C) + m1 * e.ldc * (e.c_bf16 ? 2 : 4);
-  if (e.C2) f.C2 = reinterpret_cast<char*>(e.C2) + m1 * e.ldc2 * (e.c2_bf16 ? 2 : 4);
-  if (e.R) f.R = reinterpret_cast<const char*>(e.R) + m1 * e.ldr * (e.r_bf16 ? 2 : 4);
-  if (e.AUX) f.AUX = reinterpret_cast<const char*>(e.AUX) + m1 * e.ldaux * (e.aux_bf16 ? 2 : 4);
-  if (e.colsum_part) f.colsum_part = e.colsum_part + (m1 / 128) * g.N;
-  return gemm_fast2_shape_ok(*rest);
-}
-
 int gemm_fast_launch(const GemmArgs& g, hipStream_t s) {
   if (use_tile2(g)) return gemm_fast2_launch(g, s);
-  GemmArgs a, b;
-  if (rowsplit_plan(g, &a, &b)) {
-    if (int rc = gemm_fast_launch_whole(a, s)) return rc;
-    return gemm_fast2_launch(b, s);
-  }
   return gemm_fast_launch_whole(g, s);
 }
