@@ -29,13 +29,14 @@ class GradReducer:
         self.group = group
         self.force = bool(force)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        if self.world > 1 or self.force:
-            # RCCL's all-reduce kernels hold a few dozen CUs while a bucket is in flight, and a 256x256-tile
-            # GEMM / attention-backward workgroup needs a whole CU: with the persistent grids (a FIXED tile list per workgroup)
-            # the workgroups that find their CU taken would start only when another one has walked
-            # its whole list.  One tile per workgroup lets the dispatcher balance over the free CUs.
-            from ._lib import load
-            load().vitmi_set_persistent_grids(0)
+        # RCCL's all-reduce kernels hold a few dozen CUs while a bucket is in flight, and a 256x256-tile
+        # GEMM / attention-backward workgroup needs a whole CU: with the persistent grids (a FIXED list of
+        # tiles / pairs per workgroup) the workgroups that find their CU taken would start only when
+        # another one has walked its whole list.  So the grids are switched to one tile per workgroup
+        # (vitmi_set_persistent_grids(0): the dispatcher balances over the free CUs) from the first
+        # bucket's launch until finish(); the forward pass, the start of the backward and the optimizer
+        # — ordered before / after the exchange on the compute stream — keep the persistent form.
+        self._comm_active = False
         self.min_bucket = int(min_bucket_elems)
         self._pending_lo: Optional[int] = None
         self._pending_hi: Optional[int] = None
@@ -65,6 +66,10 @@ class GradReducer:
         lo, hi = self._pending_lo, self._pending_hi
         self._pending_lo = self._pending_hi = None
         buf = self.pack.grad[lo:hi]
+        if not self._comm_active:
+            from ._lib import load
+            load().vitmi_set_persistent_grids(0)
+            self._comm_active = True
         self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self.launched.append((lo, hi))
 
@@ -72,8 +77,12 @@ class GradReducer:
         """Order the current stream after every outstanding bucket."""
         self._flush()
         for w in self._works:
-            w.wait()
+            w.wait()                      # the compute stream waits; kernels launched from here on run after the exchange
         self._works.clear()
+        if self._comm_active:
+            from ._lib import load
+            load().vitmi_set_persistent_grids(1)
+            self._comm_active = False
 
     def broadcast_parameters(self, src: int = 0) -> None:
         if self.world > 1:
