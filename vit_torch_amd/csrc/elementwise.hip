@@ -421,6 +421,9 @@ extern "C" int vitmi_colsum(const void* x, int dtype, int64_t M, int64_t N, int6
   VITMI_REQUIRE(x && out && M > 0 && N > 0 && ld >= N, VITMI_E_BADARG, "colsum: bad argument");
   VITMI_REQUIRE(workspace && workspace_bytes >= vitmi_colsum_workspace(M, N), VITMI_E_WORKSPACE, "colsum: workspace too small");
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  // a short fp32 matrix (the per-row-block partial sums the GEMM / attention epilogues leave: 256-400 rows)
+  // IS a partial buffer: fold it directly, one launch instead of two
+  if (dtype == VITMI_F32 && M <= 2048) return vitmi_reduce_rows(reinterpret_cast<const float*>(x), (int)M, N, ld, out, stream);
   const int S = colsum_splits(M);
   float* part = reinterpret_cast<float*>(workspace);
   const bool vec = (N % 4 == 0) && (ld % 4 == 0) && is_aligned(x, 4 * dtype_size(dtype));
