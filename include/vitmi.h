@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VITMI_VERSION 103
+#define VITMI_VERSION 104
 
 enum { VITMI_F32 = 0, VITMI_BF16 = 1 };
 
