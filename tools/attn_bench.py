@@ -55,8 +55,12 @@ for spec in specs:
             ops.attn_bwd(qkv, O, do, lse, dqkv, B, N, H, hd, scale, dbias_part=part)
             torch.cuda.synchronize()
             raw.vitmi_debug_attn_stamps(None)
-            t = buf.cpu().view(64, 8)[:, :5]
+            t8 = buf.cpu().view(64, 8)
+            t = t8[:, :5]
             d = (t[:, 1:] - t[:, :-1]).float()
             print("   fused %7.1f us; median cycles over 64 mid-launch workgroups: stage %d, K frags + zero dQ %d, "
                   "loop %d, stores + bias sums %d" % ((tb,) + tuple(d.median(0).values.tolist())))
+            fine = torch.stack([t8[:, 5] - t8[:, 3], t8[:, 6] - t8[:, 5], t8[:, 7] - t8[:, 6], t8[:, 4] - t8[:, 7]], 1).float()
+            print("      store phase: rows to LDS + barrier %d, next loads issued %d, store loop %d, bias sums + drain %d"
+                  % tuple(fine.median(0).values.tolist()))
     raw.vitmi_debug_attn_bwd(-1)

@@ -777,7 +777,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16* __restr
   // diagnostic timeline (armed by tools/attn_bench.py --stamps only): 64 mid-launch pairs
   const int dbg_slot = bh - npairs / 2;            // steady state, not the cold start
   const bool dbg_on = dbg != nullptr && dbg_slot >= 0 && dbg_slot < 64;
-  unsigned long long tl[5] = {0, 0, 0, 0, 0};
+  unsigned long long tl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (dbg_on) tl[0] = attn_stamp();
   // V fragments of the own keys straight from memory (first used in the main loop: their round
   // trip runs under the commit; staged a pair ahead they would cost 16 registers across it)
@@ -949,7 +949,9 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16* __restr
   const int bh_next = bh + (int)gridDim.x;
   // unconditional (the last pair loads itself again, unused): under a branch the staged registers
   // of THIS pair would stay live across the main loop as the other input of the merge (spills)
+  if (dbg_on) tl[5] = attn_stamp();               // rows committed to LDS + barrier
   issue_loads(min(bh_next, npairs - 1));
+  if (dbg_on) tl[6] = attn_stamp();               // next pair's loads issued
   float dqsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int c = tid_s; c < N * CPR; c += nthr) {
     const int row = c / CPR, pc = c % CPR;
@@ -963,6 +965,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16* __restr
     *reinterpret_cast<bf16x8*>(grow + H * HD) = *reinterpret_cast<const bf16x8*>(Ql + row * QS + pc * 16);
     *reinterpret_cast<bf16x8*>(grow + 2 * H * HD) = *reinterpret_cast<const bf16x8*>(dOl + row * QS + pc * 16);
   }
+  if (dbg_on) tl[7] = attn_stamp();               // store loop issued
   if constexpr (DBIAS) {
     int dqb_col;
     const float dqb = piece_colsum8<CPR>(dqsum, tid_s & 63, &dqb_col);
@@ -983,7 +986,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16* __restr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     tl[4] = attn_stamp();
     if (tid == 0)
-      for (int i = 0; i < 5; ++i) dbg[dbg_slot * 8 + i] = tl[i];
+      for (int i = 0; i < 8; ++i) dbg[dbg_slot * 8 + i] = tl[i];
   }
   if (bh_next >= npairs) break;
   bh = bh_next;
