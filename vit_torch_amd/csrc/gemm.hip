@@ -148,17 +148,19 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs g) {
 // stream's new rows are read back at once by the LayerNorm that follows, weight-gradient tiles are small).
 static int g_c_policy = -1;
 extern "C" void vitmi_debug_gemm_store_policy(int p) { g_c_policy = p; }
+static int g_nt_min_mb = 64;         // diagnostic hook: outputs / side inputs of at least this many MB take the nt policy
+extern "C" void vitmi_debug_gemm_nt_min_mb(int mb) { g_nt_min_mb = mb > 0 ? mb : 64; }
 static int g_side_nt = -1;           // diagnostic hook: -1 = automatic (wide side inputs), 0 / 1 forced
 extern "C" void vitmi_debug_gemm_side_nt(int v) { g_side_nt = v; }
 static int side_policy(const vitmi_gemm_desc* d) {
   if (g_side_nt >= 0) return g_side_nt;
-  return d->M * d->N * 2 >= (64ll << 20) ? 1 : 0;
+  return d->M * d->N * 2 >= ((int64_t)g_nt_min_mb << 20) ? 1 : 0;
 }
 static int store_policy(const vitmi_gemm_desc* d) {
   if (g_c_policy >= 0) return g_c_policy;
   if (d->epilogue == VITMI_EPI_RESIDUAL || d->epilogue == VITMI_EPI_PATCH_POS) return 0;
   const int64_t bytes = d->M * d->N * (d->c_dtype == VITMI_BF16 ? 2 : 4);
-  return bytes >= (64ll << 20) ? 2 : 0;
+  return bytes >= ((int64_t)g_nt_min_mb << 20) ? 2 : 0;
 }
 static int build_args(const vitmi_gemm_desc* d, GemmArgs* out) {
   VITMI_REQUIRE(d, VITMI_E_BADARG, "gemm: null descriptor");
