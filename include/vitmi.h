@@ -12,7 +12,7 @@
  * Conventions
  *  - every call only ENQUEUES work on `stream`: no allocation, no sync (safe under
  *    hipGraph capture).  Calls are re-entrant across host threads and streams.  The only
- *    process-wide state is (a) a per-device table, filled under std::call_once, of the
+ *    process-wide state is (a) a per-device table, filled under a lock, of the
  *    CU count and of which kernels have had their dynamic-LDS limit raised, and (b) the
  *    `vitmi_debug_*` switches (not declared here; test / profiling hooks that select kernel
  *    variants process-wide and must not be flipped while another thread is launching);
@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VITMI_VERSION 104
+#define VITMI_VERSION 105
 
 enum { VITMI_F32 = 0, VITMI_BF16 = 1 };
 
@@ -47,12 +47,15 @@ enum {
 
 int vitmi_version(void);
 const char* vitmi_last_error_string(void);
-/* Persistent grids: by default the GEMM and attention-backward kernels launch one workgroup per CU
- * that walks a fixed list of tiles / (image, head) pairs.  A process that runs other kernels BESIDE
- * them on the same device (RCCL collectives overlapping the backward pass) must switch them off
- * (on = 0: one tile / pair per workgroup, placed by the hardware dispatcher on whatever CUs are
- * free); vit_torch_amd.ddp.GradReducer does.  Process-wide, takes effect at the next launch. */
-void vitmi_set_persistent_grids(int on);
+/* launch_flags (vitmi_gemm_desc.launch_flags, vitmi_attn_bwd): per-call launch form.
+ * By default the GEMM and attention-backward kernels launch one workgroup per CU that walks a fixed
+ * list of tiles / (image, head) pairs (persistent grids).  A caller that runs other kernels BESIDE them
+ * on the same device (RCCL collectives overlapping the backward pass: vit_torch_amd.ddp.GradReducer)
+ * passes VITMI_LAUNCH_SHARED_DEVICE for those calls: one tile / pair per workgroup, placed by the
+ * hardware dispatcher on whatever CUs are free.  Results are bit-identical either way.  The choice is
+ * an argument of the call (it was a process-wide switch in ABI 104): concurrent engines, threads and
+ * streams cannot race on it. */
+enum { VITMI_LAUNCH_SHARED_DEVICE = 1 };
 
 /* ---------------------------------------------------------------- GEMM ---
  * C[M,N] = epilogue( sum_k A(m,k) * B(n,k) ), fp32 accumulation.
@@ -126,6 +129,7 @@ typedef struct vitmi_gemm_desc {
    * erf/exp evaluation.  Same function of the same pre-activation either way
    * (torch.nn.GELU backward); a C2 written with one value must be read with the same. */
   int32_t aux_is_derivative;
+  int32_t launch_flags;        /* VITMI_LAUNCH_* (0 = default)                 */
 } vitmi_gemm_desc;
 
 int vitmi_gemm(const vitmi_gemm_desc* d, void* stream);
@@ -186,7 +190,8 @@ int64_t vitmi_attn_bwd_dbias_rows(int64_t B, int64_t N);
 int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout,
                    const float* lse, void* dqkv, int dtype,
                    int64_t B, int64_t N, int64_t H, int64_t hd, float scale,
-                   float* dbias_part, void* workspace, size_t workspace_bytes, void* stream);
+                   float* dbias_part, int32_t launch_flags,
+                   void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------- CaiT ops --
  * Talking-heads softmax (models/cait.py:118-122) on score tensors [B,H,N,ld] (row length
@@ -279,6 +284,15 @@ int vitmi_patchify(const float* x, int64_t sb, int64_t sc, int64_t sh, int64_t s
                    int64_t B, int64_t C, int64_t H, int64_t W, int64_t p,
                    int cls_rows, void* stream);
 
+/* Bicubic resize of pos_embed to the input's patch grid (upstream DINO interpolate_pos_encoding, the
+ * module loaded at models/vision_all.py:156; oracle/vit_ref.py:110-127) as a row-sparse fp32 product:
+ *   dst[r, 0:D) = sum_{e in [row_ptr[r], row_ptr[r+1])} w[e] * src[col[e], 0:D),  r < rows.
+ * The tables depend only on the two grids and are built by the host (vit_torch_amd/posembed.py: 16
+ * taps per output position, aten's bicubic arithmetic); the transposed table gives the backward
+ * pass (fixed entry order per row: deterministic).  D, ld_src, ld_dst multiples of 4. */
+int vitmi_pos_resample(const float* src, int64_t ld_src, const int32_t* row_ptr, const int32_t* col,
+                       const float* w, float* dst, int64_t ld_dst, int64_t rows, int64_t D, void* stream);
+
 /* out[n] = sum_m x[m*ld + n]  (bias gradients, pos_embed/cls gradients) */
 size_t vitmi_colsum_workspace(int64_t M, int64_t N);
 int vitmi_colsum(const void* x, int dtype, int64_t M, int64_t N, int64_t ld,
@@ -318,6 +332,23 @@ int vitmi_image_ingest(const void* src_u8_nhwc, float* dst_nchw, const int32_t* 
 int vitmi_adam(float* p, const float* g, float* m, float* v, void* p_shadow_bf16, float* state,
                int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                int decoupled, float grad_scale, void* stream);
+
+/* The remaining entries of the reference's optimizer table (utils_network.py:119-126), same conventions
+ * as vitmi_adam (flat fp32 buffers, optional bf16 shadow refreshed in the pass, grad_scale on g first,
+ * device-side step count state[0] advanced BEFORE the update where the rule depends on the step).
+ * vitmi_adagrad: torch.optim.Adagrad (:123; lr_decay 0, eps 1e-10, initial accumulator 0 by default).
+ * vitmi_adadelta: torch.optim.Adadelta (:122; rho 0.9, eps 1e-6).
+ * vitmi_adabelief: adabelief_pytorch.AdaBelief as configured at :125 (eps 1e-16, betas (0.9, 0.999),
+ *   weight_decouple, rectify; amsgrad off, fixed_decay off, degenerated_to_sgd on).  That package is
+ *   not in this container: the rule is restated from the published algorithm (Zhuang et al. 2020) and
+ *   checked against a torch restatement of it (oracle/optim_ref.py) — parity unpinned. */
+int vitmi_adagrad(float* p, const float* g, float* sum, void* p_shadow_bf16, float* state, int64_t n, float lr,
+                  float lr_decay, float eps, float weight_decay, float grad_scale, void* stream);
+int vitmi_adadelta(float* p, const float* g, float* square_avg, float* acc_delta, void* p_shadow_bf16, int64_t n,
+                   float lr, float rho, float eps, float weight_decay, float grad_scale, void* stream);
+int vitmi_adabelief(float* p, const float* g, float* m, float* s, void* p_shadow_bf16, float* state, int64_t n,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled, int rectify,
+                    float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

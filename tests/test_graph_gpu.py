@@ -40,8 +40,7 @@ def test_graph_replay_matches_eager_steps(lib):
     # the capture ran warm-up + capture passes on the first batch: restart from the initial state
     with torch.no_grad():
         m2.engine().pack.flat.copy_(start)
-    for st in opt2._mom.values():
-        st.zero_()
+    opt2.reset_state()
     graphed = [step(x, y).item() for x, y in data]
     assert graphed == pytest.approx(eager, rel=1e-5, abs=1e-6), (graphed, eager)
     torch.testing.assert_close(m2.engine().pack.flat, p_eager, rtol=1e-5, atol=1e-6)

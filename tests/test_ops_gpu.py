@@ -826,16 +826,12 @@ def test_attention_bwd_persistent_pair_walk(ops, lib):
     lse = torch.empty(B * H * N, device="cuda")
     ops.attn_fwd(QKV, O, lse, B, N, H, hd, scale)
     outs = []
-    try:
-        for persist in (1, 0):
-            lib.vitmi_set_persistent_grids(persist)
-            dqkv = torch.full((B, N, 3 * H * hd), float("nan"), device="cuda").to(bt)
-            part = torch.full((ops.attn_bwd_dbias_rows(B, N), 3 * H * hd), float("nan"), device="cuda")
-            ops.attn_bwd(QKV, O, DO, lse, dqkv, B, N, H, hd, scale, dbias_part=part)
-            outs.append((dqkv.float().cpu(), part.cpu()))
-            assert torch.isfinite(outs[-1][0]).all() and torch.isfinite(outs[-1][1]).all()
-    finally:
-        lib.vitmi_set_persistent_grids(1)
+    for flags in (0, L.LAUNCH_SHARED_DEVICE):          # per-call launch form (ABI 105)
+        dqkv = torch.full((B, N, 3 * H * hd), float("nan"), device="cuda").to(bt)
+        part = torch.full((ops.attn_bwd_dbias_rows(B, N), 3 * H * hd), float("nan"), device="cuda")
+        ops.attn_bwd(QKV, O, DO, lse, dqkv, B, N, H, hd, scale, dbias_part=part, launch_flags=flags)
+        outs.append((dqkv.float().cpu(), part.cpu()))
+        assert torch.isfinite(outs[-1][0]).all() and torch.isfinite(outs[-1][1]).all()
     assert torch.equal(outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1], outs[1][1])
     qr = qkv.clone().requires_grad_(True)

@@ -14,6 +14,13 @@ raw.vitmi_debug_gemm_timeline.argtypes = [ctypes.c_void_p, ctypes.c_int]
 raw.vitmi_debug_gemm_tail(0)       # plain launch: no split tail
 EPI = {"store": _lib.EPI_STORE, "gelu": _lib.EPI_BIAS_GELU, "res": _lib.EPI_RESIDUAL, "dgelu": _lib.EPI_DGELU}
 for spec in sys.argv[1:]:
+    if spec.startswith("stagger="):                 # start stagger of the short-list workgroups, permille of a tile time
+        raw.vitmi_debug_gemm_stagger(int(spec[8:]))
+        print(f"--- stagger {spec[8:]}")
+        continue
+    if spec.startswith("phases="):
+        raw.vitmi_debug_gemm_stagger_phases(int(spec[7:]))
+        continue
     if spec.startswith("rfold="):                   # residual fold on (1) / off (0) for the specs that follow
         raw.vitmi_debug_gemm_rfold(int(spec[6:]))
         print(f"--- rfold {spec[6:]}")
@@ -34,7 +41,7 @@ for spec in sys.argv[1:]:
     elif epi == "dgelu":
         kw.update(aux=torch.randn((M, N), device="cuda").to(torch.bfloat16))
     nb = (M // 256) * (N // 256)
-    buf = torch.zeros(64 + 4 * nb, dtype=torch.int64, device="cuda")
+    buf = torch.zeros(64 + 8 * nb, dtype=torch.int64, device="cuda")
     for _ in range(3):
         ops.gemm(A, B, C, **kw)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -50,16 +57,16 @@ for spec in sys.argv[1:]:
         ops.gemm(A, B, C, **kw)
     torch.cuda.synchronize()
     raw.vitmi_debug_gemm_timeline(None, 64)
-    t = buf.cpu().numpy()[64:].reshape(nb, 4).astype(np.float64)
+    t = buf.cpu().numpy()[64:].reshape(nb, 8).astype(np.float64)
     ok = t[:, 0] > 0
     print(f"{spec}: {nb} tiles, {us:.1f} us per launch unstamped; stamped blocks {int(ok.sum())}")
-    # shader clock: cycles vs wall clock between block ends on the same XCD (counters are per XCD)
-    for x in range(1):
-        idx = np.arange(nb)[ok & (np.arange(nb) % 8 == x)]
-        a, b = idx[np.argmin(t[idx, 3])], idx[np.argmax(t[idx, 3])]
-        ghz = (t[b, 2] - t[a, 2]) / ((t[b, 3] - t[a, 3]) * 10.0) if t[b, 3] > t[a, 3] else float("nan")
-        span_us = (t[b, 3] - t[a, 3]) / 100.0
-        print(f"  xcd {x}: first->last block end {span_us:.1f} us wall, shader clock {ghz:.3f} GHz")
+    # shader clock under this kernel: each workgroup's (exit - entry) in shader cycles (s_memtime) over the same
+    # span on the 100 MHz wall clock (s_memrealtime), both stamped by the same wave (guide: DVFS give-back, item 6)
+    life_c, life_w = t[ok, 5] - t[ok, 0], (t[ok, 6] - t[ok, 4]) * 10.0      # cycles, ns
+    good = life_w > 0
+    ghz = life_c[good] / life_w[good]
+    print(f"  shader clock (per-workgroup entry->exit, {int(good.sum())} workgroups): median {np.median(ghz):.3f} GHz "
+          f"(p10 {np.percentile(ghz, 10):.3f}, p90 {np.percentile(ghz, 90):.3f}); workgroup life {np.median(life_w) / 1e3:.1f} us")
     main, ep = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1]
     order = np.argsort(t[:, 3], kind="stable")
     q = max(nb // 8, 1)

@@ -14,6 +14,7 @@ LIB_PATH = HERE / "libvitmi.so"
 F32, BF16 = 0, 1
 EPI_STORE, EPI_BIAS_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_PATCH_POS = 0, 1, 2, 3, 4
 GEMM_AUTO, GEMM_GENERIC, GEMM_FAST = 0, 1, 2
+LAUNCH_SHARED_DEVICE = 1
 
 c_i64, c_i32, c_f32, c_vp, c_sz = C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_size_t
 
@@ -39,6 +40,7 @@ class GemmDesc(C.Structure):
         ("rowscale", c_vp), ("rows_per_group", c_i64),
         ("colsum_part", c_vp),
         ("aux_is_derivative", c_i32),
+        ("launch_flags", c_i32),
     ]
 
     def __init__(self, *a, **k):
@@ -50,7 +52,6 @@ class GemmDesc(C.Structure):
 SIGNATURES = {
     "vitmi_version": (C.c_int, []),
     "vitmi_last_error_string": (C.c_char_p, []),
-    "vitmi_set_persistent_grids": (None, [C.c_int]),
     "vitmi_gemm": (C.c_int, [C.POINTER(GemmDesc), c_vp]),
     "vitmi_gemm_uses_fast": (C.c_int, [C.POINTER(GemmDesc)]),
     "vitmi_gemm_workspace": (c_sz, [C.POINTER(GemmDesc)]),
@@ -64,7 +65,7 @@ SIGNATURES = {
     "vitmi_attn_bwd_workspace": (c_sz, [c_i64, c_i64, c_i64]),
     "vitmi_attn_bwd_dbias_rows": (c_i64, [c_i64, c_i64]),
     "vitmi_attn_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_i64,
-                                 c_f32, c_vp, c_vp, c_sz, c_vp]),
+                                 c_f32, c_vp, c_i32, c_vp, c_sz, c_vp]),
     "vitmi_th_softmax_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp]),
     "vitmi_th_softmax_bwd_workspace": (c_sz, [c_i64, c_i64, c_i64]),
     "vitmi_th_softmax_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int,
@@ -87,6 +88,7 @@ SIGNATURES = {
     "vitmi_scale_cast": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, c_vp, c_i64, c_vp, C.c_int, c_i64, c_i64, c_i64, c_vp]),
     "vitmi_patchify": (C.c_int, [c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, C.c_int, c_i64, c_i64, c_i64,
                                  c_i64, c_i64, c_i64, C.c_int, c_vp]),
+    "vitmi_pos_resample": (C.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]),
     "vitmi_colsum_workspace": (c_sz, [c_i64, c_i64]),
     "vitmi_colsum": (C.c_int, [c_vp, C.c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_sz, c_vp]),
     "vitmi_softmax_xent": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
@@ -95,6 +97,10 @@ SIGNATURES = {
                                      c_i64, c_vp]),
     "vitmi_adam": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, C.c_int,
                              c_f32, c_vp]),
+    "vitmi_adagrad": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp]),
+    "vitmi_adadelta": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp]),
+    "vitmi_adabelief": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, C.c_int,
+                                  C.c_int, c_f32, c_vp]),
 }
 
 _lib = None

@@ -29,6 +29,8 @@ SOURCES = [
     "layernorm.hip",
     "elementwise.hip",
     "ingest.hip",
+    "posembed.hip",
+    "optim.hip",
     "attention.hip",
     "attention_f32.hip",
     "cait_ops.hip",

@@ -331,6 +331,14 @@ class CaitEngine:
 
     # --------------------------------------------------------------- backward ---
     def backward(self, dout):
+        try:
+            self._backward(dout)
+        except BaseException:
+            if self.reducer is not None:
+                self.reducer.abort()
+            raise
+
+    def _backward(self, dout):
         s = self.saved
         if s is None:
             raise VitmiError("backward called without a saved forward (or called twice)")

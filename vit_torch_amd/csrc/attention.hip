@@ -1078,8 +1078,8 @@ extern "C" int64_t vitmi_attn_bwd_dbias_rows(int64_t B, int64_t N) {
 
 extern "C" int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
                               void* dqkv, int dtype, int64_t B, int64_t N, int64_t H, int64_t hd,
-                              float scale, float* dbias_part, void* workspace, size_t workspace_bytes,
-                              void* stream_) {
+                              float scale, float* dbias_part, int32_t launch_flags, void* workspace,
+                              size_t workspace_bytes, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   VITMI_REQUIRE(out && dout && lse && dqkv, VITMI_E_BADARG, "attn_bwd: null argument");
   VITMI_REQUIRE(!dbias_part || dtype == VITMI_BF16, VITMI_E_DTYPE, "attn_bwd: dbias_part is produced by the bf16 kernels only");
@@ -1094,8 +1094,8 @@ extern "C" int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout
   const int nw = attn_waves(N);
   if (attn_bwd_fused_ok(N, hd)) {
     // one workgroup per CU walking pairs bh, bh + grid, ... (see the kernel); one pair per workgroup
-    // when persistent grids are off (data-parallel runs: RCCL kernels hold CUs)
-    const int64_t grid_f = vitmi_persist_on() && B * H > vitmi_cu_count() ? vitmi_cu_count() : B * H;
+    // when the call carries VITMI_LAUNCH_SHARED_DEVICE (data-parallel runs: RCCL kernels hold CUs)
+    const int64_t grid_f = vitmi_persist_on(launch_flags) && B * H > vitmi_cu_count() ? vitmi_cu_count() : B * H;
 #define LAUNCH_FUSED(HDV, DB)                                                                            \
     do {                                                                                                 \
       auto kern = attn_bwd_fused_kernel<HDV, DB>;                                                        \

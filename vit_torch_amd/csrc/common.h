@@ -23,9 +23,9 @@ int vitmi_check_launch(const char* what);
 // state besides the vitmi_debug_* switches): CU count of the current device, and the
 // dynamic-LDS limit of a kernel raised once per (kernel, device).
 int vitmi_cu_count();
-// persistent grids (one workgroup per CU walking a fixed list of tiles / (image, head) pairs); switched off by
-// vitmi_debug_gemm_persist(0), which the data-parallel path does: RCCL kernels hold CUs while a bucket is in flight
-int vitmi_persist_on();
+// persistent grids (one workgroup per CU walking a fixed list of tiles / (image, head) pairs) unless the call
+// carries VITMI_LAUNCH_SHARED_DEVICE (other kernels, e.g. RCCL's, hold CUs); vitmi_debug_gemm_persist overrides
+int vitmi_persist_on(int launch_flags);
 int vitmi_raise_dynamic_lds(const void* kern, int bytes, const char* who);
 // out[c] = sum_{r<S} part[r*ld + c], c < N (elementwise.hip)
 int vitmi_reduce_rows(const float* part, int S, int64_t N, int64_t ld, float* out, hipStream_t stream);

@@ -51,10 +51,15 @@ int vitmi_cu_count() {
   return cus;
 }
 
-static std::atomic<int> g_persist{1};
-extern "C" void vitmi_set_persistent_grids(int on) { g_persist.store(on != 0, std::memory_order_relaxed); }
-extern "C" void vitmi_debug_gemm_persist(int on) { vitmi_set_persistent_grids(on); }   // name the tools use
-int vitmi_persist_on() { return g_persist.load(std::memory_order_relaxed); }
+// test / profiling hook (not part of the ABI): -1 = follow each call's launch_flags (default), 0 = force
+// one tile / pair per workgroup, 1 = force the persistent grids
+static std::atomic<int> g_persist_override{-1};
+extern "C" void vitmi_debug_gemm_persist(int on) { g_persist_override.store(on < 0 ? -1 : (on != 0), std::memory_order_relaxed); }
+int vitmi_persist_on(int launch_flags) {
+  const int o = g_persist_override.load(std::memory_order_relaxed);
+  if (o >= 0) return o;
+  return (launch_flags & VITMI_LAUNCH_SHARED_DEVICE) ? 0 : 1;
+}
 
 int vitmi_raise_dynamic_lds(const void* kern, int bytes, const char* who) {
   const int dev = current_device();

@@ -32,6 +32,8 @@ struct GemmArgs {
   int vec_a, vec_b;               // operand rows are 16-B aligned: vector staging allowed
   int rfold;                      // gemm_fast: stream the fp32 residual through LDS during the main loop
   int band;                       // gemm_fast: column-band width of the tile order (0 = row-major)
+  int launch_flags;               // VITMI_LAUNCH_*
+  int stag_cycles, stag_phases;   // gemm_fast, persistent walk: start delay of the workgroups with the shorter tile list
   EpiArgs e;
 };
 

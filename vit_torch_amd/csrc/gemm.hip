@@ -183,6 +183,8 @@ static int build_args(const vitmi_gemm_desc* d, GemmArgs* out) {
   g.ws = d->workspace; g.ws_bytes = d->workspace_bytes;
   g.rfold = 0;
   g.band = 0;
+  g.stag_cycles = 0; g.stag_phases = 1;
+  g.launch_flags = d->launch_flags;
   g.dbg = g_gemm_dbg;
   g.dbg_blocks = g_gemm_dbg_blocks;
   g.batch = d->batch > 1 ? d->batch : 1;

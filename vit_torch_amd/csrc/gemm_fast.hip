@@ -355,7 +355,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
   const bool dbg_tl = g.dbg != nullptr && (int)blockIdx.x < g.dbg_blocks && wave == 0;
   const bool dbg = g.dbg != nullptr && blockIdx.x == 0;   // wave-uniform
   unsigned long long tl0 = 0;
-  if (dbg_tl) tl0 = stamp();
+  if (dbg_tl) {
+    tl0 = stamp();
+    unsigned long long rt0;                        // 100 MHz wall clock at entry: with the pair at exit, the shader clock under THIS kernel
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0) :: "memory");
+    if (lane == 0) g.dbg[64 + blockIdx.x * 8 + 4] = rt0;
+  }
 
   // ---- per-PIPE staging plans and fragment offsets (lane parts are tile independent)
   constexpr bool RINGP = PIPE == 1 || PIPE == 3;
@@ -422,6 +427,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
   int64_t m0 = (int64_t)mt_ * BM, n0 = (int64_t)nt_ * BN;
   start_tile(m0, n0);
   bool prefetched = false;                         // the tile's prologue DMAs were issued before an epilogue
+  // Start stagger: a launch of q full rounds plus a remainder leaves most workgroups one tile short of
+  // the longest list, i.e. idle for a tile time at the end.  Those workgroups instead start late by a
+  // phase-dependent part of that slack, so that their epilogues (HBM bursts, no MFMA) fall into the main
+  // loops of the others instead of all 256 CUs hitting HBM at the same moment.
+  if constexpr (PERSIST) {
+    if (g.stag_cycles > 0) {
+      const int mine = (x_len - slot + gx - 1) / gx, longest = (x_len + gx - 1) / gx;
+      if (mine < longest) {
+        const unsigned long long t0 = stamp();
+        const unsigned long long d = (unsigned long long)g.stag_cycles * (unsigned)(1 + slot % g.stag_phases) / (unsigned)g.stag_phases;
+        while (stamp() - t0 < d) __builtin_amdgcn_s_sleep(16);
+      }
+    }
+  }
 
 #pragma unroll 1
   for (;;) {
@@ -711,11 +730,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
     wait_vm(0);                                    // stores retired = the wave could end here
     const unsigned long long tl2 = stamp();
     if (lane == 0) {
-      g.dbg[64 + blockIdx.x * 4 + 0] = tl0; g.dbg[64 + blockIdx.x * 4 + 1] = tl1;
-      g.dbg[64 + blockIdx.x * 4 + 2] = tl2;
+      g.dbg[64 + blockIdx.x * 8 + 0] = tl0; g.dbg[64 + blockIdx.x * 8 + 1] = tl1;
+      g.dbg[64 + blockIdx.x * 8 + 2] = tl2;
       unsigned long long rt;                       // 100 MHz wall clock: relates cycles to time
       asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt) :: "memory");
-      g.dbg[64 + blockIdx.x * 4 + 3] = rt;
+      g.dbg[64 + blockIdx.x * 8 + 3] = rt;
     }
   }
   // ---- next tile
@@ -727,6 +746,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
     n0 = n0n;
     prefetched = true;
   }
+  }
+  if (dbg_tl) {                                    // exit of the workgroup (all its tiles): cycles and wall clock
+    wait_vm(0);
+    const unsigned long long tlE = stamp();
+    unsigned long long rtE;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rtE) :: "memory");
+    if (lane == 0) { g.dbg[64 + blockIdx.x * 8 + 5] = tlE; g.dbg[64 + blockIdx.x * 8 + 6] = rtE; }
   }
 }
 
@@ -830,6 +856,10 @@ static int g_rfold_override = -1;
 // diagnostic / test hook: 0 = epilogue reads the residual (round-1 behaviour), 1 / -1 = fold it in
 extern "C" void vitmi_debug_gemm_rfold(int mode) { g_rfold_override = mode; }
 
+// diagnostic hook / default of the start stagger: permille of an estimated tile time (0 = off) and phases
+static int g_stagger_permille = 0, g_stagger_phases = 2;
+extern "C" void vitmi_debug_gemm_stagger(int permille) { g_stagger_permille = permille; }
+extern "C" void vitmi_debug_gemm_stagger_phases(int n) { g_stagger_phases = n > 0 ? n : 1; }
 static int g_pipe_override = -1;
 // diagnostic / test hook: force the main-loop variant (0, 1, 2) or -1 = automatic
 extern "C" void vitmi_debug_gemm_pipe(int mode) { g_pipe_override = mode; }
@@ -874,9 +904,9 @@ template <int MODE, typename TC, bool SPLITK, int PIPE>
 constexpr int lds_bytes() {
   return SPLITK ? 2 * STAGE_BYTES : RF_LDS;
 }
-// vitmi_debug_gemm_persist (core.cpp): 0 = one tile per workgroup (grid = tiles), 1 = persistent grid
-static int persistent_grid(int nwg) {
-  if (!vitmi_persist_on()) return nwg;
+// launch_flags & VITMI_LAUNCH_SHARED_DEVICE: one tile per workgroup (grid = tiles); else the persistent grid
+static int persistent_grid(int nwg, int launch_flags) {
+  if (!vitmi_persist_on(launch_flags)) return nwg;
   int cus = vitmi_cu_count();
   cus -= cus % 8;                                  // whole XCD rows: every XCD gets the same number of workgroups
   if (cus < 8) cus = 8;
@@ -911,6 +941,11 @@ int launch_p(const GemmArgs& g_in, hipStream_t stream) {
   const int tiles_m = (int)(g.M / BM), tiles_n = (int)(g.N / BN);
   const int nwg = tiles_m * tiles_n;
   g.band = band_for(g, tiles_m, tiles_n);
+  {   // tile time estimate in shader cycles: ~3.6 k per 64-deep k-step + an epilogue
+    const int64_t est = (g.K / BK) * 3600 + 8000;
+    g.stag_cycles = (int)(est * g_stagger_permille / 1000);
+    g.stag_phases = g_stagger_phases;
+  }
   if constexpr (MODE == VITMI_EPI_STORE && sizeof(TC) == 4) {
     int splits, ksps;
     splitk_plan(nwg, (int)(g.K / BK), &splits, &ksps);
@@ -942,7 +977,7 @@ int launch_p(const GemmArgs& g_in, hipStream_t stream) {
       if (int rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(kmain), LDSM, "gemm_fast")) return rc;
       if (int rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(ktail), 2 * STAGE_BYTES, "gemm_fast(tail)")) return rc;
       float* ws = reinterpret_cast<float*>(g.ws);
-      hipLaunchKernelGGL(kmain, dim3(persistent_grid(full)), dim3(NTHREADS), LDSM, stream, g, tiles_n, full, full, 0, (float*)nullptr, 0);
+      hipLaunchKernelGGL(kmain, dim3(persistent_grid(full, g.launch_flags)), dim3(NTHREADS), LDSM, stream, g, tiles_n, full, full, 0, (float*)nullptr, 0);
       int rc = vitmi_check_launch("gemm_fast_kernel(full rounds)");
       if (rc) return rc;
       hipLaunchKernelGGL(ktail, dim3(rem * splits), dim3(NTHREADS), 2 * STAGE_BYTES, stream, g, tiles_n, rem * splits, rem, ksps, ws, full);
@@ -954,7 +989,7 @@ int launch_p(const GemmArgs& g_in, hipStream_t stream) {
   auto kern = gemm_fast_kernel<A_KM, B_KM, MODE, TC, false, PIPE>;
   constexpr int LDSK = lds_bytes<MODE, TC, false, PIPE>();
   if (int rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(kern), LDSK, "gemm_fast")) return rc;
-  hipLaunchKernelGGL(kern, dim3(persistent_grid(nwg)), dim3(NTHREADS), LDSK, stream, g, tiles_n, nwg, nwg, 0, (float*)nullptr, 0);
+  hipLaunchKernelGGL(kern, dim3(persistent_grid(nwg, g.launch_flags)), dim3(NTHREADS), LDSK, stream, g, tiles_n, nwg, nwg, 0, (float*)nullptr, 0);
   return vitmi_check_launch("gemm_fast_kernel");
 }
 

@@ -32,11 +32,13 @@ class GradReducer:
         # RCCL's all-reduce kernels hold a few dozen CUs while a bucket is in flight, and a 256x256-tile
         # GEMM / attention-backward workgroup needs a whole CU: with the persistent grids (a FIXED list of
         # tiles / pairs per workgroup) the workgroups that find their CU taken would start only when
-        # another one has walked its whole list.  So the grids are switched to one tile per workgroup
-        # (vitmi_set_persistent_grids(0): the dispatcher balances over the free CUs) from the first
-        # bucket's launch until finish(); the forward pass, the start of the backward and the optimizer
-        # — ordered before / after the exchange on the compute stream — keep the persistent form.
-        self._comm_active = False
+        # another one has walked its whole list.  So from the first bucket's launch until finish() the
+        # engine passes VITMI_LAUNCH_SHARED_DEVICE with every GEMM / attention-backward call (one tile per
+        # workgroup: the dispatcher balances over the free CUs); the forward pass, the start of the
+        # backward and the optimizer — ordered before / after the exchange on the compute stream — keep
+        # the persistent form.  The flag travels with each call (`launch_flags`, ABI 105): nothing
+        # process-wide is switched, so an exception in backward cannot leave another engine degraded.
+        self.comm_active = False
         self.min_bucket = int(min_bucket_elems)
         self._pending_lo: Optional[int] = None
         self._pending_hi: Optional[int] = None
@@ -66,10 +68,7 @@ class GradReducer:
         lo, hi = self._pending_lo, self._pending_hi
         self._pending_lo = self._pending_hi = None
         buf = self.pack.grad[lo:hi]
-        if not self._comm_active:
-            from ._lib import load
-            load().vitmi_set_persistent_grids(0)
-            self._comm_active = True
+        self.comm_active = True
         self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self.launched.append((lo, hi))
 
@@ -79,11 +78,24 @@ class GradReducer:
         for w in self._works:
             w.wait()                      # the compute stream waits; kernels launched from here on run after the exchange
         self._works.clear()
-        if self._comm_active:
-            from ._lib import load
-            load().vitmi_set_persistent_grids(1)
-            self._comm_active = False
+        self.comm_active = False
+
+    def launch_flags(self) -> int:
+        """What the engine passes as `launch_flags` right now (vitmi.h VITMI_LAUNCH_*)."""
+        from ._lib import LAUNCH_SHARED_DEVICE
+        return LAUNCH_SHARED_DEVICE if self.comm_active else 0
+
+    def abort(self) -> None:
+        """After an exception inside backward: join what was launched, drop what was pending."""
+        self._pending_lo = self._pending_hi = None
+        try:
+            for w in self._works:
+                w.wait()
+        finally:
+            self._works.clear()
+            self.comm_active = False
 
     def broadcast_parameters(self, src: int = 0) -> None:
         if self.world > 1:
             dist.broadcast(self.pack.flat, src=src, group=self.group)
+            self.pack.invalidate_shadow()     # the master was written behind the version counters (ADVICE r2)

@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 
 from .loss import CrossEntropyLoss
-from .optim import FusedAdamW, FusedSGD
+from .optim import FusedAdaBelief, FusedAdadelta, FusedAdagrad, FusedAdamW, FusedSGD
 
 
 class LRSchedule:
@@ -90,6 +90,9 @@ class Network:
         "adam": lambda params, lr: FusedAdamW(params, lr=lr, weight_decay=0.0, decoupled=False),   # utils_network.py:121
         "adamw": lambda params, lr: FusedAdamW(params, lr=lr),                                     # utils_network.py:124
         "torch_adamw": lambda params, lr: torch.optim.AdamW(params, lr=lr),
+        "adadelta": lambda params, lr: FusedAdadelta(params, lr=lr),                               # utils_network.py:122
+        "adagrad": lambda params, lr: FusedAdagrad(params, lr=lr),                                 # utils_network.py:123
+        "adabelief": lambda params, lr: FusedAdaBelief(params, lr=lr),                             # utils_network.py:125
     }
 
     def __init__(self, model, opt="sgd", loss_fn=None, lr=1e-3, lr_type="step", lr_step=10, lr_gamma=0.5,
@@ -107,7 +110,7 @@ class Network:
         self.epochs = epochs
         if opt not in self.optimizer_fns:
             raise ValueError(f"optimizer `{opt}` is not supported")
-        if opt in ("sgd", "adam", "adamw"):     # the flat buffers exist after the engine is built
+        if not opt.startswith("torch_"):     # the flat buffers exist after the engine is built
             if not hasattr(self.model, "engine"):
                 raise ValueError(f"optimizer `{opt}` (fused) needs a vit_torch_amd model or ClassifierHead")
             self.model.engine()

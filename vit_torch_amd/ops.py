@@ -51,7 +51,8 @@ def workspace(nbytes: int, device) -> torch.Tensor:
 
 def gemm(A, B, C_out, *, a_kmajor=True, b_kmajor=True, epilogue=EPI_STORE, bias=None, R=None,
          gamma=None, aux=None, C2=None, pos=None, n_tok=0, cls=None, alpha=1.0, accumulate=False,
-         impl=GEMM_AUTO, rowscale=None, rows_per_group=0, colsum_part=None, aux_deriv=False):
+         impl=GEMM_AUTO, rowscale=None, rows_per_group=0, colsum_part=None, aux_deriv=False,
+         launch_flags=0):
     """C = epilogue(op(A) @ op(B)^T); see vitmi_gemm in include/vitmi.h."""
     _need_cuda(A, B, C_out)
     assert A.dim() == 2 and B.dim() == 2 and C_out.dim() == 2
@@ -101,6 +102,7 @@ def gemm(A, B, C_out, *, a_kmajor=True, b_kmajor=True, epilogue=EPI_STORE, bias=
         assert tuple(colsum_part.shape) == ((M + 127) // 128, N)
         d.colsum_part = colsum_part.data_ptr()
     d.aux_is_derivative = int(bool(aux_deriv))
+    d.launch_flags = int(launch_flags)
     lib = load()
     need = lib.vitmi_gemm_workspace(C.byref(d))
     if need:
@@ -199,7 +201,7 @@ def attn_bwd_dbias_rows(B, N) -> int:
     return int(load().vitmi_attn_bwd_dbias_rows(B, N))
 
 
-def attn_bwd(qkv, out, dout, lse, dqkv, B, N, H, hd, scale, dbias_part=None):
+def attn_bwd(qkv, out, dout, lse, dqkv, B, N, H, hd, scale, dbias_part=None, launch_flags=0):
     """dbias_part (bf16 only): fp32 [attn_bwd_dbias_rows(B, N), 3*H*hd] partial column sums of dqkv."""
     _need_cuda(qkv, out, dout, dqkv)
     assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and dqkv.is_contiguous()
@@ -210,7 +212,7 @@ def attn_bwd(qkv, out, dout, lse, dqkv, B, N, H, hd, scale, dbias_part=None):
     ws = workspace(lib.vitmi_attn_bwd_workspace(B, N, H), qkv.device)
     check(lib.vitmi_attn_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
                              dqkv.data_ptr(), dtype_code(qkv), B, N, H, hd, float(scale), _ptr(dbias_part),
-                             ws.data_ptr(), ws.numel(), _stream()), "vitmi_attn_bwd")
+                             int(launch_flags), ws.data_ptr(), ws.numel(), _stream()), "vitmi_attn_bwd")
     return dqkv
 
 
@@ -232,6 +234,23 @@ def patchify(x, out, p, cls_rows):
     sb, sc, sh, sw = x.stride()
     check(load().vitmi_patchify(x.data_ptr(), sb, sc, sh, sw, out.data_ptr(), dtype_code(out), out.shape[1],
                                 B, Cc, H, W, p, int(cls_rows), _stream()), "vitmi_patchify")
+    return out
+
+
+def pos_resample(src, table, out=None):
+    """out[r] = sum_e w[e] * src[col[e]] over row r's entries of `table` = (row_ptr, col, w, rows):
+    the bicubic pos_embed resize, or with the transposed table its backward (posembed.py)."""
+    row_ptr, col, w, rows = table
+    _need_cuda(src, row_ptr, col, w)
+    assert src.dtype == torch.float32 and src.dim() == 2 and src.stride(1) == 1
+    assert row_ptr.dtype == torch.int32 and col.dtype == torch.int32 and w.dtype == torch.float32
+    assert row_ptr.numel() == rows + 1
+    D = src.shape[1]
+    if out is None:
+        out = torch.empty((rows, D), dtype=torch.float32, device=src.device)
+    assert out.dtype == torch.float32 and tuple(out.shape) == (rows, D) and out.stride(1) == 1
+    check(load().vitmi_pos_resample(src.data_ptr(), src.stride(0), row_ptr.data_ptr(), col.data_ptr(), w.data_ptr(),
+                                    out.data_ptr(), out.stride(0), rows, D, _stream()), "vitmi_pos_resample")
     return out
 
 
@@ -289,6 +308,32 @@ def adam(p, g, m, v, shadow, state, lr, beta1, beta2, eps, weight_decay, decoupl
     check(load().vitmi_adam(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(shadow), state.data_ptr(),
                             p.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
                             int(bool(decoupled)), float(grad_scale), _stream()), "vitmi_adam")
+
+
+def adagrad(p, g, acc, shadow, state, lr, lr_decay, eps, weight_decay, grad_scale=1.0):
+    _need_cuda(p, g, acc, state)
+    assert p.dtype == g.dtype == acc.dtype == state.dtype == torch.float32 and p.numel() == g.numel() == acc.numel()
+    check(load().vitmi_adagrad(p.data_ptr(), g.data_ptr(), acc.data_ptr(), _ptr(shadow), state.data_ptr(), p.numel(),
+                               float(lr), float(lr_decay), float(eps), float(weight_decay), float(grad_scale),
+                               _stream()), "vitmi_adagrad")
+
+
+def adadelta(p, g, square_avg, acc_delta, shadow, lr, rho, eps, weight_decay, grad_scale=1.0):
+    _need_cuda(p, g, square_avg, acc_delta)
+    assert p.dtype == g.dtype == square_avg.dtype == acc_delta.dtype == torch.float32
+    assert p.numel() == g.numel() == square_avg.numel() == acc_delta.numel()
+    check(load().vitmi_adadelta(p.data_ptr(), g.data_ptr(), square_avg.data_ptr(), acc_delta.data_ptr(), _ptr(shadow),
+                                p.numel(), float(lr), float(rho), float(eps), float(weight_decay), float(grad_scale),
+                                _stream()), "vitmi_adadelta")
+
+
+def adabelief(p, g, m, s, shadow, state, lr, beta1, beta2, eps, weight_decay, decoupled, rectify, grad_scale=1.0):
+    _need_cuda(p, g, m, s, state)
+    assert p.dtype == g.dtype == m.dtype == s.dtype == state.dtype == torch.float32
+    assert p.numel() == g.numel() == m.numel() == s.numel()
+    check(load().vitmi_adabelief(p.data_ptr(), g.data_ptr(), m.data_ptr(), s.data_ptr(), _ptr(shadow), state.data_ptr(),
+                                 p.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+                                 int(bool(decoupled)), int(bool(rectify)), float(grad_scale), _stream()), "vitmi_adabelief")
 
 
 # ------------------------------------------------------------------ CaiT ops ---

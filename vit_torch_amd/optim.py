@@ -1,6 +1,7 @@
-"""optim.SGD(momentum=0.9) (utils_network.py:120, step at :442) as ONE fused HIP
-kernel per model over the flat parameter / gradient / momentum buffers, which
-also refreshes the bf16 weight shadow in the same pass."""
+"""The reference's optimizer table (/root/reference/utils_network.py:119-126: sgd with momentum
+0.9, adam, adadelta, adagrad, adamw, adabelief; step at :442) as ONE fused HIP kernel per
+contiguous span of a model's flat parameter / gradient / state buffers, which also refreshes
+the bf16 weight shadow in the same pass."""
 from __future__ import annotations
 
 import weakref
@@ -42,68 +43,168 @@ def _check_disjoint(param_groups):
             seen.add(id(p))
 
 
-class FusedSGD(torch.optim.Optimizer):
-    """Same update rule as torch.optim.SGD(lr, momentum, dampening=0, nesterov=False,
-    weight_decay=0): buf = momentum*buf + g (buf starts at 0, i.e. buf_1 = g_1);
-    p -= lr*buf.  `grad_scale` multiplies g first (1/world_size after a SUM
-    all-reduce)."""
+class _StepCounters:
+    """Device-side step counts (fp32 [1], advanced by the kernels: HIP-graph safe), one per span a
+    kernel runs over.  When the spans change between steps (a parameter frozen or unfrozen, param
+    groups edited) the counts the elements have ALREADY taken are carried over: the old counters
+    are read back once, and a new span whose elements disagree is cut where the count changes — so
+    bias corrections stay those of each element's own history (torch keeps `step` per parameter),
+    and an element that joins late starts at 0 with its zero state."""
 
-    def __init__(self, params, lr=1e-3, momentum=0.9, grad_scale=1.0):
-        defaults = dict(lr=lr, momentum=momentum, grad_scale=grad_scale)
+    def __init__(self):
+        self.ticks = {}          # (start, end) -> tensor
+
+    def spans(self, runs, device):
+        """[(start, end, tick)] covering `runs`."""
+        if all(r in self.ticks for r in runs) and len(runs) == len(self.ticks):
+            return [(s, e, self.ticks[(s, e)]) for s, e in runs]
+        old = sorted((s, e, float(t.item())) for (s, e), t in self.ticks.items())    # rare: one sync
+
+        def count_at(i):
+            for s, e, c in old:
+                if s <= i < e:
+                    return c
+            return 0.0
+
+        cuts = sorted({b for s, e, _ in old for b in (s, e)})
+        new = {}
+        for s, e in runs:
+            edges = [s] + [c for c in cuts if s < c < e] + [e]
+            piece_lo, piece_c = edges[0], count_at(edges[0])
+            for a, b in zip(edges[:-1], edges[1:]):
+                c = count_at(a)
+                if c != piece_c:
+                    new[(piece_lo, a)] = piece_c
+                    piece_lo, piece_c = a, c
+            new[(piece_lo, e)] = piece_c
+        self.ticks = {k: torch.full((1,), c, dtype=torch.float32, device=device) for k, c in new.items()}
+        return [(s, e, t) for (s, e), t in sorted(self.ticks.items())]
+
+
+class _FusedFlat(torch.optim.Optimizer):
+    """Walks the param groups, finds the flat spans, keeps `n_state` state arrays per pack."""
+    n_state = 0
+    counted = False                 # the rule depends on the step count
+
+    def __init__(self, params, defaults):
         super().__init__(params, defaults)
         _check_disjoint(self.param_groups)
-        self._mom = weakref.WeakKeyDictionary()     # pack -> momentum buffer (pack layout)
+        self._st = weakref.WeakKeyDictionary()     # pack -> ([state arrays], {group index: _StepCounters})
+
+    def _state_init(self, flat, group):
+        return [torch.zeros_like(flat) for _ in range(self.n_state)]
+
+    def _apply(self, group, p, g, st, shadow, tick):
+        raise NotImplementedError
+
+    @torch.no_grad()
+    def reset_state(self):
+        """State arrays and step counts back to their initial values, in place (the device buffers a
+        captured HIP graph points at stay the same)."""
+        for arrays, counters in self._st.values():
+            for a in arrays:
+                a.fill_(getattr(self, "_fill", 0.0))
+            for c in counters.values():
+                for t in c.ticks.values():
+                    t.zero_()
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             for pack, runs in _group_runs(group):
-                buf = self._mom.get(pack)
-                if buf is None:
-                    buf = torch.zeros_like(pack.flat)
-                    self._mom[pack] = buf
-                for s, e in runs:
-                    ops.sgd_momentum(pack.flat[s:e], pack.grad[s:e], buf[s:e],
-                                     pack.shadow[s:e] if pack.shadow is not None else None,
-                                     group["lr"], group["momentum"], group["grad_scale"])
-                if pack.shadow is not None:
-                    pack.mark_shadow_current()     # the kernel wrote master and shadow together
+                st = self._st.get(pack)
+                if st is None:
+                    st = self._st[pack] = (self._state_init(pack.flat, group), {})
+                arrays, counters = st
+                if self.counted:
+                    spans = counters.setdefault(gi, _StepCounters()).spans(runs, pack.flat.device)
+                else:
+                    spans = [(s, e, None) for s, e in runs]
+                for s, e, tick in spans:
+                    self._apply(group, pack.flat[s:e], pack.grad[s:e], [a[s:e] for a in arrays],
+                                pack.shadow[s:e] if pack.shadow is not None else None, tick)
         return loss
 
 
-class FusedAdamW(torch.optim.Optimizer):
+class FusedSGD(_FusedFlat):
+    """Same update rule as torch.optim.SGD(lr, momentum, dampening=0, nesterov=False,
+    weight_decay=0): buf = momentum*buf + g (buf starts at 0, i.e. buf_1 = g_1);
+    p -= lr*buf.  `grad_scale` multiplies g first (1/world_size after a SUM
+    all-reduce)."""
+    n_state = 1
+
+    def __init__(self, params, lr=1e-3, momentum=0.9, grad_scale=1.0):
+        super().__init__(params, dict(lr=lr, momentum=momentum, grad_scale=grad_scale))
+
+    def _apply(self, group, p, g, st, shadow, tick):
+        ops.sgd_momentum(p, g, st[0], shadow, group["lr"], group["momentum"], group["grad_scale"])
+
+
+class FusedAdamW(_FusedFlat):
     """`optim.AdamW(params, lr)` / `optim.Adam(params, lr)` of the reference's optimizer table
     (/root/reference/utils_network.py:121,124; every linear-evaluation log uses AdamW) as ONE
     kernel over the flat buffers of a ParamPack, with the bf16 shadow refreshed in the same
     pass.  torch's defaults and update order; the step count lives on the device, so the
     step can be replayed from a HIP graph.  `decoupled=False` gives Adam (L2 decay)."""
+    n_state = 2
+    counted = True
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, decoupled=True,
                  grad_scale=1.0):
-        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, decoupled=decoupled,
-                        grad_scale=grad_scale)
-        super().__init__(params, defaults)
-        _check_disjoint(self.param_groups)
-        self._st = weakref.WeakKeyDictionary()      # pack -> (m, v, {run start: step counter})
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, decoupled=decoupled,
+                                      grad_scale=grad_scale))
 
-    @torch.no_grad()
-    def step(self, closure=None):
-        loss = closure() if closure is not None else None
-        for group in self.param_groups:
-            for pack, runs in _group_runs(group):
-                st = self._st.get(pack)
-                if st is None:
-                    st = (torch.zeros_like(pack.flat), torch.zeros_like(pack.flat), {})
-                    self._st[pack] = st
-                b1, b2 = group["betas"]
-                for s, e in runs:
-                    tick = st[2].get((s, e))
-                    if tick is None:    # the kernel advances it: one counter per range it runs over
-                        tick = st[2][(s, e)] = torch.zeros(1, dtype=torch.float32, device=pack.flat.device)
-                    ops.adam(pack.flat[s:e], pack.grad[s:e], st[0][s:e], st[1][s:e],
-                             pack.shadow[s:e] if pack.shadow is not None else None, tick, group["lr"], b1, b2,
-                             group["eps"], group["weight_decay"], group["decoupled"], group["grad_scale"])
-                if pack.shadow is not None:
-                    pack.mark_shadow_current()
-        return loss
+    def _apply(self, group, p, g, st, shadow, tick):
+        b1, b2 = group["betas"]
+        ops.adam(p, g, st[0], st[1], shadow, tick, group["lr"], b1, b2, group["eps"], group["weight_decay"],
+                 group["decoupled"], group["grad_scale"])
+
+
+class FusedAdagrad(_FusedFlat):
+    """`optim.Adagrad(params, lr)` (/root/reference/utils_network.py:123), torch's defaults."""
+    n_state = 1
+    counted = True
+
+    def __init__(self, params, lr=1e-2, lr_decay=0.0, weight_decay=0.0, initial_accumulator_value=0.0, eps=1e-10,
+                 grad_scale=1.0):
+        super().__init__(params, dict(lr=lr, lr_decay=lr_decay, weight_decay=weight_decay, eps=eps,
+                                      initial_accumulator_value=initial_accumulator_value, grad_scale=grad_scale))
+
+    def _state_init(self, flat, group):
+        self._fill = float(group["initial_accumulator_value"])
+        return [torch.full_like(flat, self._fill)]
+
+    def _apply(self, group, p, g, st, shadow, tick):
+        ops.adagrad(p, g, st[0], shadow, tick, group["lr"], group["lr_decay"], group["eps"], group["weight_decay"],
+                    group["grad_scale"])
+
+
+class FusedAdadelta(_FusedFlat):
+    """`optim.Adadelta(params, lr)` (/root/reference/utils_network.py:122), torch's defaults."""
+    n_state = 2
+
+    def __init__(self, params, lr=1.0, rho=0.9, eps=1e-6, weight_decay=0.0, grad_scale=1.0):
+        super().__init__(params, dict(lr=lr, rho=rho, eps=eps, weight_decay=weight_decay, grad_scale=grad_scale))
+
+    def _apply(self, group, p, g, st, shadow, tick):
+        ops.adadelta(p, g, st[0], st[1], shadow, group["lr"], group["rho"], group["eps"], group["weight_decay"],
+                     group["grad_scale"])
+
+
+class FusedAdaBelief(_FusedFlat):
+    """`AdaBelief(params, lr, eps=1e-16, betas=(0.9, 0.999), weight_decouple=True, rectify=True)`
+    (/root/reference/utils_network.py:125).  The adabelief_pytorch package is not in this container:
+    the rule is restated from the published algorithm (include/vitmi.h, vitmi_adabelief)."""
+    n_state = 2
+    counted = True
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-16, weight_decay=0.0, weight_decouple=True,
+                 rectify=True, grad_scale=1.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                                      weight_decouple=weight_decouple, rectify=rectify, grad_scale=grad_scale))
+
+    def _apply(self, group, p, g, st, shadow, tick):
+        b1, b2 = group["betas"]
+        ops.adabelief(p, g, st[0], st[1], shadow, tick, group["lr"], b1, b2, group["eps"], group["weight_decay"],
+                      group["weight_decouple"], group["rectify"], group["grad_scale"])

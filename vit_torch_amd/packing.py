@@ -61,8 +61,8 @@ class ParamPack:
     # written a parameter since the last cast / fused-optimizer pass: every Parameter keeps its
     # OWN version counter (`p.data = view` does not tie it to the flat buffer's), so the key
     # covers the flat buffer and every parameter: p.add_(), torch.optim steps,
-    # load_state_dict(), nn.init all bump one of them.  Our own kernels write through raw
-    # pointers and report what they refreshed (mark_shadow_current).  Writes through a
+    # load_state_dict(), nn.init all bump one of them.  Our own optimizer kernels write master
+    # AND shadow together through raw pointers (no version moves, none needs to).  Writes through a
     # detached alias (`p.data.copy_()`) carry a fresh counter nobody can observe: call
     # invalidate_shadow() after those.
     def _version_key(self):
@@ -79,13 +79,6 @@ class ParamPack:
             from . import ops
             ops.cast(self.flat, self.shadow)
             self._shadow_key = key
-
-    def mark_shadow_current(self) -> None:
-        """Called by a kernel that rewrote master AND shadow together over some span (FusedSGD,
-        FusedAdamW).  Such kernels write through raw pointers, so no version torch can see moved:
-        the key still matches exactly when the shadow was current before the pass, and a
-        pending outside write (another parameter changed through torch) stays pending."""
-        return None
 
     def invalidate_shadow(self) -> None:
         self._shadow_key = None

@@ -381,6 +381,14 @@ class SwinEngine:
 
     # --------------------------------------------------------------- backward ---
     def backward(self, dout):
+        try:
+            self._backward(dout)
+        except BaseException:
+            if self.reducer is not None:
+                self.reducer.abort()
+            raise
+
+    def _backward(self, dout):
         s = self.saved
         if s is None:
             raise VitmiError("backward called without a saved forward (or called twice)")

@@ -21,12 +21,12 @@ from typing import List, Optional
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import ops
 from ._lib import (EPI_BIAS_GELU, EPI_DGELU, EPI_PATCH_POS, EPI_RESIDUAL, EPI_STORE, GEMM_AUTO,
                    VitmiError)
 from .packing import ParamPack
+from .posembed import tables_for
 
 _DT = {"bf16": torch.bfloat16, "fp32": torch.float32, torch.bfloat16: torch.bfloat16,
        torch.float32: torch.float32}
@@ -171,6 +171,8 @@ def engine_gemm(eng, A, B, C, **k):
     # fp32 (parity) mode keeps the pre-activation, as the reference's autograd does.
     if k.get("epilogue") in (EPI_BIAS_GELU, EPI_DGELU):
         k.setdefault("aux_deriv", eng.T == torch.bfloat16)
+    if eng.reducer is not None:             # gradient buckets in flight: share the device with RCCL's kernels
+        k.setdefault("launch_flags", eng.reducer.launch_flags())
     if eng.profile is None:
         return ops.gemm(A, B, C, impl=eng.gemm_impl, **k)
     akm, bkm = k.get("a_kmajor", True), k.get("b_kmajor", True)
@@ -254,24 +256,16 @@ class VitEngine:
         self.reducer.section_ready(ps)
 
     def _pos_for(self, gh, gw):
-        """pos_embed at the input's patch grid: as stored, or the bicubic resize
-        upstream DINO applies ([recall]); returns (pos [N,D] fp32, graph or None)."""
+        """pos_embed at the input's patch grid: as stored, or the bicubic resize upstream DINO
+        applies ([recall]; oracle/vit_ref.py:110-127) through the tap-table kernel
+        (posembed.py, vitmi_pos_resample); returns (pos [N,D] fp32, tables or None)."""
         m = self.model
         pos = self.pack.f32(m.pos_embed)
         n_stored = pos.shape[1] - 1
         if gh * gw == n_stored and gh == gw:
             return pos.reshape(-1, pos.shape[-1]), None
-        side = int(math.sqrt(n_stored))
-        D = pos.shape[-1]
-        leaf = pos.detach().clone().requires_grad_(True)
-        with torch.enable_grad():
-            patch = leaf[:, 1:].reshape(1, side, side, D).permute(0, 3, 1, 2)
-            patch = F.interpolate(patch, scale_factor=((gh + 0.1) / side, (gw + 0.1) / side),
-                                  mode="bicubic")
-            assert patch.shape[-2] == gh and patch.shape[-1] == gw
-            eff = torch.cat((leaf[:, :1], patch.permute(0, 2, 3, 1).reshape(1, -1, D)), dim=1)
-            eff = eff.reshape(-1, D).contiguous()
-        return eff.detach(), (leaf, eff)
+        tabs = tables_for(n_stored, gh, gw, pos.device)
+        return ops.pos_resample(pos.reshape(-1, pos.shape[-1]), tabs.fwd), tabs
 
     # -- forward -------------------------------------------------------------
     def forward(self, x, save: bool):
@@ -297,7 +291,7 @@ class VitEngine:
 
         patches = new(M, Kp, T)
         ops.patchify(x, patches, p, cls_rows=1)
-        pos, pos_graph = self._pos_for(gh, gw)
+        pos, pos_tabs = self._pos_for(gh, gw)
         X = new(M, D, R)
         self._gemm(patches, self._w(conv.weight).view(D, Kp), X, epilogue=EPI_PATCH_POS,
                    bias=self.pack.f32(conv.bias) if conv.bias is not None else None,
@@ -359,11 +353,19 @@ class VitEngine:
         if save:
             self.saved = dict(B=B, N=N, M=M, D=D, H=H, hd=hd, Kp=Kp, patches=patches, blocks=blocks,
                               Xf=X, meanf=meanf, rstdf=rstdf, acts=acts, pres=pres,
-                              pos_graph=pos_graph)
+                              pos_tabs=pos_tabs)
         return cur
 
     # -- backward ------------------------------------------------------------
     def backward(self, dout):
+        try:
+            self._backward(dout)
+        except BaseException:
+            if self.reducer is not None:
+                self.reducer.abort()
+            raise
+
+    def _backward(self, dout):
         s = self.saved
         if s is None:
             raise VitmiError("backward called without a saved forward (or called twice)")
@@ -447,7 +449,8 @@ class VitEngine:
             dqkv_part = None
             if fused_bias and a.qkv.bias is not None:
                 dqkv_part = torch.empty((ops.attn_bwd_dbias_rows(B, N), 3 * D), dtype=torch.float32, device=dev)
-            ops.attn_bwd(qkv, O, dO, lse, dqkv, B, N, H, hd, a.scale, dbias_part=dqkv_part)
+            ops.attn_bwd(qkv, O, dO, lse, dqkv, B, N, H, hd, a.scale, dbias_part=dqkv_part,
+                         launch_flags=self.reducer.launch_flags() if self.reducer is not None else 0)
             self._gemm(dqkv, ln1, pk.g(a.qkv.weight), a_kmajor=False, b_kmajor=False)
             if a.qkv.bias is not None:
                 ops.colsum(dqkv_part if dqkv_part is not None else dqkv, pk.g(a.qkv.bias))
@@ -466,12 +469,10 @@ class VitEngine:
         dpos = torch.empty(N * D, dtype=torch.float32, device=dev)
         ops.colsum(G, dpos, M=B, N=N * D, ld=N * D)          # sum over the batch
         ops.cast(dpos[:D], pk.g(m.cls_token).view(-1))       # d cls = d pos[0]
-        if s["pos_graph"] is None:
+        if s["pos_tabs"] is None:
             ops.cast(dpos, pk.g(m.pos_embed).view(-1))
-        else:   # through the bicubic resize (parameter-only, once per step)
-            leaf, eff = s["pos_graph"]
-            (gleaf,) = torch.autograd.grad(eff, leaf, dpos.view_as(eff))
-            pk.g(m.pos_embed).copy_(gleaf)
+        else:   # through the bicubic resize: the transposed tap table
+            ops.pos_resample(dpos.view(N, D), s["pos_tabs"].bwd, pk.g(m.pos_embed).view(-1, D))
         self._gemm(Gb, s["patches"], pk.g(conv.weight).view(D, Kp), a_kmajor=False, b_kmajor=False)
         if conv.bias is not None:
             ops.colsum(dpos[D:].view(N - 1, D), pk.g(conv.bias))  # CLS rows carry no conv bias
