@@ -169,6 +169,11 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+# enforced per mode (bench exits non-zero on a miss): fp32 = the north-star bar; bf16 = stated budget of the benchmarked mode
+PARITY_TOL = {"fp32": {"logits_rel": 1e-3, "loss_diff": 1e-3, "gradnorm_rel": 1e-3, "grad_cos_min": 0.999999},
+              "bf16": {"logits_rel": 2e-2, "loss_diff": 1e-2, "gradnorm_rel": 2.5e-2, "grad_cos_min": 0.99}}
+
+
 def parity_check(arch, img, residual, batch=2):
     """HIP step vs the CPU oracle on identical seeded weights / inputs, both modes (outside the
     timed region).  The oracle is the checker here, never the thing measured."""
@@ -198,7 +203,7 @@ def parity_check(arch, img, residual, batch=2):
         logits = m(x.cuda())
         loss = CrossEntropyLoss()(logits, y.cuda())
         loss.backward()
-        worst = 0.0
+        worst, cos_min = 0.0, 1.0
         gmax = max(pr.grad.double().norm().item() for pr in ref.parameters() if pr.grad is not None)
         for (n, pr), (_, pm) in zip(ref.named_parameters(), m.named_parameters()):
             gr = pr.grad.double().norm().item()
@@ -206,12 +211,22 @@ def parity_check(arch, img, residual, batch=2):
             # bias): the reference holds rounding noise there, nothing to be relative to
             if gr < 1e-6 * gmax:
                 continue
-            worst = max(worst, abs(pm.grad.double().norm().item() - gr) / gr)
-        out[mode] = {"logits_rel": float(f"{(logits.float().cpu() - lo).abs().max().item() / lo.abs().max().item():.3e}"),
-                     "loss_diff": float(f"{abs(loss.item() - lr.item()):.3e}"),
-                     "gradnorm_rel": float(f"{worst:.3e}")}
+            gm = pm.grad.double().cpu().flatten()
+            worst = max(worst, abs(gm.norm().item() - gr) / gr)
+            cos_min = min(cos_min, float(gm @ pr.grad.double().flatten()) / (gm.norm().item() * gr))
+        res = {"logits_rel": float(f"{(logits.float().cpu() - lo).abs().max().item() / lo.abs().max().item():.3e}"),
+               "loss_diff": float(f"{abs(loss.item() - lr.item()):.3e}"),
+               "gradnorm_rel": float(f"{worst:.3e}"),
+               "grad_cos_min": float(f"{cos_min:.6f}")}
+        tol = PARITY_TOL[mode]
+        res["pass"] = bool(res["logits_rel"] <= tol["logits_rel"] and res["loss_diff"] <= tol["loss_diff"]
+                           and res["gradnorm_rel"] <= tol["gradnorm_rel"] and res["grad_cos_min"] >= tol["grad_cos_min"])
+        out[mode] = res
         del m
-    out["tolerance"] = {"fp32": 1e-3, "bf16": "reported, not met: bf16 operands round at 2^-9"}
+    out["tolerance"] = PARITY_TOL
+    out["tolerance_note"] = ("fp32 mode = the parity claim (north-star bar 1e-3 on logits).  bf16 operands round at 2^-9 and "
+                             "cannot meet 1e-3: the bf16 bounds are the enforced budget of the benchmarked mode (tests/ assert "
+                             "the same numbers), gradients must also point the same way (worst per-parameter cosine)")
     torch.cuda.empty_cache()
     return out
 
@@ -442,6 +457,13 @@ def main():
             "roofline": roof, "cpu_baseline": cpu, "parity": parity, "residual_alt": alt,
         }
         print(json.dumps(out), flush=True)
+        if parity is not None and not (parity["fp32"]["pass"] and parity["bf16"]["pass"]):
+            # the line is printed (the numbers are the evidence), but a run whose numerics miss the stated bounds fails
+            print("bench.py: parity outside the enforced tolerance: " + json.dumps({k: parity[k] for k in ("fp32", "bf16")}),
+                  file=sys.stderr, flush=True)
+            if ddp:
+                dist.destroy_process_group()
+            raise SystemExit(3)
     if ddp:
         dist.destroy_process_group()
 

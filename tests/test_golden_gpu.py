@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from util import assert_close
+from util import assert_close, cosine, grad_sample_index
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -391,6 +391,8 @@ def swin_tiny_model(compute):
 
 
 ZERO_GRAD = ("proj_l.bias", "attn.k.bias")      # analytically zero gradients (softmax shift invariance)
+BF16_COS_FULL = 0.995     # the same over 256 sampled entries of a full-size (12-26 block) model; printed by the test
+BF16_COS = 0.999          # per-parameter cosine of bf16-mode gradients with the fp32 reference's (measured >= 0.9995)
 
 
 @pytest.mark.parametrize("fam,compute", [("cait", "fp32"), ("swin", "fp32"), ("cait", "bf16"), ("swin", "bf16")])
@@ -410,7 +412,7 @@ def test_tiny_models_from_reference_fixture(fam, compute):
     fp32 = compute == "fp32"
     e = assert_close("logits", out, top["logits"], 1e-4 if fp32 else 1.2e-2)
     assert abs(loss.item() - float(top["loss"])) < (1e-4 if fp32 else 5e-3)
-    worst = 0.0
+    worst, worst_cos = 0.0, (1.0, "")
     for n, p in m.named_parameters():
         want = g["grad"][n]
         if n.endswith(ZERO_GRAD):
@@ -420,13 +422,73 @@ def test_tiny_models_from_reference_fixture(fam, compute):
         else:
             gn, gw = p.grad.float().norm().item(), want.norm().item()
             worst = max(worst, abs(gn - gw) / max(gw, 1e-12))
+            c = cosine(p.grad, want)             # direction, not only length
+            if c < worst_cos[0]:
+                worst_cos = (c, n)
     assert worst < (3e-4 if fp32 else 2e-2), worst
-    print(f"\n{fam}_tiny[{compute}] vs reference fixture: logits {e:.2e}, worst grad {worst:.2e}")
+    assert worst_cos[0] > BF16_COS, worst_cos
+    print(f"\n{fam}_tiny[{compute}] vs reference fixture: logits {e:.2e}, worst grad {worst:.2e}, worst cosine {worst_cos}")
 
 
 def inputs(B, S, seed):
     gen = torch.Generator("cpu").manual_seed(seed)
     return torch.randn(B, 3, S, S, generator=gen), torch.randint(0, 10, (B,), generator=gen)
+
+
+def build_full_hip(name, compute):
+    """Product module of a full-size fixture, weights from the seeded initialiser."""
+    from oracle.vit_ref import seeded_init_           # the initialiser only (no oracle forward)
+    from vit_torch_amd import VisionModelZoo
+    top, g = load(name)
+    if name == "full_swin_tiny":
+        m = VisionModelZoo.get_model("swin_tiny_patch4_window7_224", pretrained=False, classifier=None,
+                                     drop_path_rate=0.0, num_classes=10, compute_dtype=compute)
+        m.head = nn.Linear(768, 10, bias=False)
+    elif name == "full_cait_S24_224":
+        m = VisionModelZoo.get_model("cait_S24_224", pretrained=False, classifier=None, compute_dtype=compute)
+        m.head = nn.Linear(384, 10, bias=False)
+        if hasattr(m, "head_dist"):
+            m.head_dist = m.head
+    else:                                             # oracle_dino_vitb16: the headline architecture
+        m = VisionModelZoo.get_model("dino_vitb16", pretrained=False, classifier=10, compute_dtype=compute)
+    seeded_init_(m, int(top["init_seed"]))
+    if "gamma" in top:
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if "gamma_" in n:
+                    p.fill_(float(top["gamma"]))
+    return m, top, g
+
+
+@pytest.mark.parametrize("name", ["full_swin_tiny", "full_cait_S24_224", "oracle_dino_vitb16"])
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+def test_full_size_sampled_gradient_entries(name, compute):
+    """Directional evidence at full size: the 256 sampled gradient entries per parameter
+    that the reference classes (Swin-T, CaiT-S24) / the oracle (ViT-B/16: upstream DINO absent) produced.
+    fp32: rel-to-max of every sample; bf16: cosine of every sample with >= 8 entries and a non-zero gradient."""
+    from vit_torch_amd import CrossEntropyLoss
+    m, top, g = build_full_hip(name, compute)
+    x, y = inputs(2, 224, int(top["input_seed"]))
+    m = m.cuda()
+    CrossEntropyLoss()(m(x.cuda()), y.cuda()).backward()
+    worst_rel, worst_cos = (0.0, ""), (1.0, "")
+    gmax = max(float(v) for v in g["gradnorm"].values())
+    for n, p in m.named_parameters():
+        want = g["gradsample"][n]
+        if float(g["gradnorm"][n]) < 1e-9 or n.endswith(ZERO_GRAD):
+            continue
+        mine = p.grad.flatten().cpu()[grad_sample_index(n, p.numel())].float()
+        if compute == "fp32":
+            e = assert_close(f"gradsample[{n}]", mine, want, 1e-3)
+            if e > worst_rel[0]:
+                worst_rel = (e, n)
+        elif want.numel() >= 8 and float(g["gradnorm"][n]) > 1e-6 * gmax:
+            c = cosine(mine, want)
+            if c < worst_cos[0]:
+                worst_cos = (c, n)
+    if compute == "bf16":
+        assert worst_cos[0] > BF16_COS_FULL, worst_cos
+    print(f"\n{name}[{compute}] sampled gradients: worst rel-to-max {worst_rel}, worst cosine {worst_cos}")
 
 
 @pytest.mark.parametrize("name", ["full_swin_tiny", "full_cait_S24_224"])

@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from util import assert_close
+from util import assert_close, cosine, grad_sample_index
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -80,6 +80,11 @@ def test_full_size_oracle_matches_reference_class(name):
             assert got < 1e-6, n
             continue
         worst = max(worst, abs(got - want) / want)
+        # direction: the sampled gradient entries the reference produced (rel-to-max of the sample + cosine)
+        smp = groups["gradsample"][n]
+        mine = p.grad.flatten()[grad_sample_index(n, p.numel())]
+        assert_close(f"gradsample[{n}]", mine, smp, 2e-4)
+        assert cosine(mine, smp) > 1 - 1e-6, n
     assert worst < 1e-4, worst
 
 

@@ -15,11 +15,12 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from util import assert_close
+from util import assert_close, grad_agreement
 
 pytestmark = pytest.mark.gpu
 
 BF16_LOGITS, BF16_LOSS, BF16_GRADNORM = 1.5e-2, 1e-2, 8e-3
+BF16_COS = 0.995            # worst per-parameter gradient cosine, bf16 mode vs the fp32 oracle (printed by the test)
 
 
 def data(B, S, seed=0):
@@ -74,6 +75,10 @@ def test_config_fp32_parity(arch, img, B):
     assert abs(loss.item() - lr.item()) < 1e-3
     worst, name = gradnorm_worst(ref, m)
     assert worst < 1e-3, (name, worst)
+    for (n, pr), (_, pm) in zip(ref.named_parameters(), m.named_parameters()):      # every entry, and the direction
+        if pr.grad.abs().max().item() > 1e-9:
+            assert_close(f"grad[{n}]", pm.grad, pr.grad, 1e-3)
+    assert grad_agreement(ref, m)[2] > 1 - 1e-6
     assert crit.last_correct.item() == (lo.argmax(-1) == y).sum().item()
     print(f"\n{arch}@{img} bs{B} fp32: logits rel {e:.2e}, loss diff {abs(loss.item() - lr.item()):.2e}, "
           f"worst grad-norm rel {worst:.2e} ({name})")
@@ -88,8 +93,10 @@ def test_config_bf16_deviation_is_bounded(arch, img, B):
     assert abs(loss.item() - lr.item()) < BF16_LOSS
     worst, name = gradnorm_worst(ref, m)
     assert worst < BF16_GRADNORM, (name, worst)
+    _, _, cmin, cname = grad_agreement(ref, m)
+    assert cmin > BF16_COS, (cname, cmin)
     print(f"\n{arch}@{img} bs{B} bf16: logits rel {e:.2e}, loss diff {abs(loss.item() - lr.item()):.2e}, "
-          f"worst grad-norm rel {worst:.2e} ({name})")
+          f"worst grad-norm rel {worst:.2e} ({name}), worst gradient cosine {cmin:.6f} ({cname})")
 
 
 # ------------------------------------------------------------- bf16 shadow freshness ---

@@ -1,0 +1,70 @@
+"""Does the bf16 residual stream TRAIN the same?  (VERDICT r02 item 3c / ADVICE r02.)
+
+dino_vits16 (12 blocks, D = 384: the depth at which a bf16 residual stream accumulates its rounding) is
+trained for 50 steps of the harness sequence zero_grad -> backward -> SGD(momentum 0.9).step()
+(/root/reference/utils_network.py:120,440-442) on four fixed 64x64 batches, three times from the same
+seeded weights: the fp32 oracle on the CPU, the HIP path with bf16 operands + fp32 residual stream, and the
+HIP path with bf16 operands + bf16 residual stream (the benchmarked mode).  The loss curves of both HIP
+runs must stay within a stated gap of the oracle's, and the bf16 stream must not be materially further from
+the oracle than the fp32 stream is.  Bounds = ~2x the gaps measured on the MI355X (printed)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+STEPS, NB, B, IMG, LR = 50, 4, 16, 64, 0.02
+MAX_GAP = 0.03            # max_t |loss_hip(t) - loss_oracle(t)|, both residual-stream dtypes
+FINAL_REL = 0.05          # |loss_hip - loss_oracle| / loss_oracle at the last step
+
+
+def batches():
+    g = torch.Generator("cpu").manual_seed(123)
+    return [(torch.randn(B, 3, IMG, IMG, generator=g), torch.randint(0, 10, (B,), generator=g)) for _ in range(NB)]
+
+
+def test_bf16_stream_trains_like_the_fp32_oracle():
+    from oracle import vit_ref
+    from vit_torch_amd import CrossEntropyLoss, FusedSGD, VisionModelZoo
+    data = batches()
+    ref = vit_ref.build("dino_vits16", classifier=10)
+    vit_ref.seeded_init_(ref, 1)
+    state = {k: v.clone() for k, v in ref.state_dict().items()}
+    torch.set_num_threads(16)
+    opt = torch.optim.SGD(ref.parameters(), lr=LR, momentum=0.9)
+    curve_ref = []
+    for t in range(STEPS):
+        x, y = data[t % NB]
+        loss = F.cross_entropy(ref(x), y)
+        opt.zero_grad(); loss.backward(); opt.step()
+        curve_ref.append(loss.item())
+    curves = {}
+    for residual in ("fp32", "bf16"):
+        m = VisionModelZoo.get_model("dino_vits16", pretrained=False, classifier=10, compute_dtype="bf16",
+                                     residual_dtype=residual)
+        m.load_state_dict(state, strict=True)
+        m = m.cuda()
+        m.engine()
+        o = FusedSGD(m.parameters(), lr=LR, momentum=0.9)
+        crit = CrossEntropyLoss()
+        dev = [(x.cuda(), y.cuda()) for x, y in data]
+        c = []
+        for t in range(STEPS):
+            x, y = dev[t % NB]
+            o.zero_grad()
+            loss = crit(m(x), y)
+            loss.backward()
+            o.step()
+            c.append(loss.item())
+        curves[residual] = c
+    gap = {r: max(abs(a - b) for a, b in zip(c, curve_ref)) for r, c in curves.items()}
+    fin = {r: abs(c[-1] - curve_ref[-1]) / max(curve_ref[-1], 1e-6) for r, c in curves.items()}
+    print(f"\noracle fp32 loss: step 1 {curve_ref[0]:.4f} -> step {STEPS} {curve_ref[-1]:.4f}")
+    for r in curves:
+        print(f"bf16 operands, {r} residual stream: step {STEPS} loss {curves[r][-1]:.4f}, max gap to the oracle over the "
+              f"curve {gap[r]:.4f}, final rel gap {fin[r]:.4f}")
+    assert curve_ref[-1] < 0.7 * curve_ref[0], "the run must actually train (loss falls) for the comparison to mean anything"
+    for r in curves:
+        assert gap[r] < MAX_GAP, (r, gap[r])
+        assert fin[r] < FINAL_REL, (r, fin[r])
+    assert gap["bf16"] < 2.0 * gap["fp32"] + 5e-3, gap

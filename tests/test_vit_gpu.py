@@ -13,12 +13,15 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from util import assert_close, rel_err
+from util import assert_close, rel_err, grad_agreement
 
 pytestmark = pytest.mark.gpu
 
 # (logits rel-to-max, |loss diff|, per-parameter grad-norm rel) by residual-stream dtype
 BF16_TOL = {"fp32": (1.2e-2, 1e-2, 8e-3), "bf16": (2e-2, 1e-2, 8e-3)}
+# worst per-parameter cosine between bf16-mode gradients and the fp32 oracle's (small 2-block model / full ViT-B/16);
+# the tests print the measured value
+BF16_COS, BF16_COS_FULL = 0.999, 0.995
 
 
 def make_pair(cfg, classifier, compute, residual="fp32", seed=1):
@@ -95,8 +98,10 @@ def test_bf16_mode_close_to_oracle(residual):
         rel = abs(gn - gn_ref) / max(gn_ref, 1e-12)
         worst = max(worst, rel)
         assert rel < BF16_TOL[residual][2], f"grad-norm[{n}]: {gn:.4g} vs {gn_ref:.4g}"
+    _, _, cmin, cname = grad_agreement(ref, m)
+    assert cmin > BF16_COS, (cname, cmin)            # direction of every parameter's gradient, not only its length
     print(f"\nbf16 mode (residual {residual}): logits rel err {e:.2e}, loss diff "
-          f"{abs(loss.item()-loss_ref.item()):.2e}, worst grad-norm rel err {worst:.2e}")
+          f"{abs(loss.item()-loss_ref.item()):.2e}, worst grad-norm rel err {worst:.2e}, worst cosine {cmin:.6f} ({cname})")
 
 
 def test_two_sgd_steps_match_torch_sgd_fp32():
@@ -171,7 +176,15 @@ def test_vitb16_full_size_fp32_logits_within_1e3():
         gn_ref, gn = pr.grad.norm().item(), pm.grad.norm().item()
         worst = max(worst, abs(gn - gn_ref) / max(gn_ref, 1e-12))
     assert worst < 1e-3
-    print(f"\nvitb16 fp32: logits rel err {e:.2e}, loss diff {abs(loss.item()-loss_ref.item()):.2e}, worst grad-norm rel {worst:.2e}")
+    # every gradient ENTRY, rel-to-max per parameter, and the direction
+    werr = 0.0
+    for (n, pr), (_, pm) in zip(ref.named_parameters(), m.named_parameters()):
+        if pr.grad.abs().max().item() > 1e-9:
+            werr = max(werr, assert_close(f"grad[{n}]", pm.grad, pr.grad, 1e-3))
+    _, _, cmin, cname = grad_agreement(ref, m)
+    assert cmin > 1 - 1e-6, (cname, cmin)
+    print(f"\nvitb16 fp32: logits rel err {e:.2e}, loss diff {abs(loss.item()-loss_ref.item()):.2e}, worst grad-norm rel {worst:.2e}, "
+          f"worst grad entry rel-to-max {werr:.2e}, worst cosine {cmin:.8f} ({cname})")
 
 
 @pytest.mark.parametrize("residual", ["fp32", "bf16"])
@@ -197,6 +210,9 @@ def test_vitb16_full_size_bf16_deviation_is_bounded(residual):
         if rel > worst:
             worst, worst_name = rel, n
     assert worst < BF16_TOL[residual][2], f"{worst_name}: {worst}"
+    _, _, cmin, cname = grad_agreement(ref, m)
+    assert cmin > BF16_COS_FULL, (cname, cmin)
+    print(f"vitb16 bf16 (residual {residual}): worst per-parameter gradient cosine {cmin:.6f} ({cname})")
     print(f"\nvitb16 bf16 (residual {residual}): logits rel err {e:.2e}, loss diff "
           f"{abs(loss.item()-loss_ref.item()):.2e}, worst grad-norm rel {worst:.2e} ({worst_name})")
 

@@ -857,7 +857,7 @@ static int g_rfold_override = -1;
 extern "C" void vitmi_debug_gemm_rfold(int mode) { g_rfold_override = mode; }
 
 // diagnostic hook / default of the start stagger: permille of an estimated tile time (0 = off) and phases
-static int g_stagger_permille = 0, g_stagger_phases = 2;
+static int g_stagger_permille = 700, g_stagger_phases = 4;     // swept inside the ViT-B/16 step (tools/sweep_bench.sh): 34.53 -> 33.98 ms
 extern "C" void vitmi_debug_gemm_stagger(int permille) { g_stagger_permille = permille; }
 extern "C" void vitmi_debug_gemm_stagger_phases(int n) { g_stagger_phases = n > 0 ? n : 1; }
 static int g_pipe_override = -1;
