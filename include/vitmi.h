@@ -325,6 +325,16 @@ int vitmi_image_ingest(const void* src_u8_nhwc, float* dst_nchw, const int32_t* 
                        const uint8_t* flip, const float* mean, const float* std, int64_t B, int64_t H,
                        int64_t W, int64_t C, int64_t S, int64_t pad, int64_t fill, void* stream);
 
+/* vitmi_image_ingest fused with vitmi_patchify: the same per-sample transform of the uint8 NHWC batch written
+ * straight into the patch rows [B*(cls_rows + (S/p)^2), out_ld] (dtype out_dtype, k = c*p*p + i*p + j, columns
+ * beyond C*p*p zero, CLS placeholder rows zero) that the patch-embedding GEMM contracts — no fp32 NCHW
+ * intermediate (utils_datasets.py:553-582 + models/swin.py:440-448 / the DINO patch conv).  Bit-identical to the
+ * two calls in sequence.  p % 4 == 0, S % p == 0. */
+int vitmi_ingest_patchify(const void* src_u8_nhwc, void* out, int out_dtype, int64_t out_ld, const int32_t* off_y,
+                          const int32_t* off_x, const uint8_t* flip, const float* mean, const float* std,
+                          int64_t B, int64_t H, int64_t W, int64_t C, int64_t S, int64_t pad, int64_t fill,
+                          int64_t p, int cls_rows, void* stream);
+
 /* optim.Adam / optim.AdamW step (utils_network.py:121,124; torch defaults betas (0.9, 0.999),
  * eps 1e-8, AdamW weight_decay 1e-2) over a flat buffer.  state[0] (device, fp32) is the step
  * count: it is advanced by this call BEFORE the update, so a captured HIP graph replays the

@@ -46,6 +46,12 @@ def _worker(rank, world, port, q):
         red.section_ready(list(blk.parameters()))
     red.section_ready([model.cls_token, model.pos_embed] + list(model.patch_embed.parameters()))
     red.finish()
+    # buckets go out in REVERSE layer order (head + norm first, embeddings last), each one
+    # ending where the previous one began in the flat gradient buffer (named_parameters order)
+    order_ok = all(red.launched[i][0] == red.launched[i + 1][1] for i in range(len(red.launched) - 1))
+    spans = {"first": red.launched[0], "last": red.launched[-1], "head_hi": pack.span(list(model.head.parameters()))[1],
+             "emb_lo": pack.span([model.cls_token])[0]}
+    order_ok = order_ok and spans["first"][1] == spans["head_hi"] == pack.total and spans["last"][0] == spans["emb_lo"] == 0
     covered = sorted(red.launched)
     ok_cover = covered[0][0] == 0 and covered[-1][1] == pack.total and all(
         covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
@@ -53,7 +59,7 @@ def _worker(rank, world, port, q):
     for n, p in model.named_parameters():
         got = pack.g(p) / world          # FusedSGD applies grad_scale = 1/world
         worst = max(worst, (got - want[n]).abs().max().item() / (want[n].abs().max().item() + 1e-12))
-    q.put((rank, ok_cover, len(covered), worst))
+    q.put((rank, ok_cover and order_ok, len(covered), worst))
     dist.destroy_process_group()
 
 
@@ -69,7 +75,7 @@ def test_grad_reducer_world2_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     for rank, ok_cover, nb, worst in res:
-        assert ok_cover, f"rank {rank}: buckets do not tile the flat gradient buffer"
+        assert ok_cover, f"rank {rank}: buckets do not tile the flat gradient buffer in reverse layer order"
         assert nb >= 2, "expected more than one bucket"
         assert worst < 1e-5, f"rank {rank}: averaged gradients differ from the global-batch gradients ({worst})"
 

@@ -68,6 +68,43 @@ def test_bucketed_allreduce_overlapped_with_backward_matches_plain_step(nccl_wor
     assert torch.equal(p0, p1), "an all-reduce over one rank must not change the step"
 
 
+def test_graphed_step_captures_the_gradient_exchange(nccl_world_of_one, lib):
+    """GraphedStep with a GradReducer on the engine — the bucketed async all-reduces are
+    captured inside the hipGraph (RCCL's stream joins the capture) and a replayed step equals the eager one."""
+    from vit_torch_amd import CrossEntropyLoss, FusedSGD, GraphedStep, VisionTransformer
+    from vit_torch_amd.ddp import GradReducer
+
+    def make():
+        torch.manual_seed(5)
+        m = VisionTransformer(img_size=32, patch_size=16, embed_dim=128, depth=3, num_heads=2, num_classes=10,
+                              compute_dtype="bf16").cuda()
+        m.head = torch.nn.Linear(128, 10, bias=False).cuda()
+        eng = m.engine()
+        eng.reducer = GradReducer(eng.pack, min_bucket_elems=1 << 16, force=True)
+        return m, eng, FusedSGD(m.parameters(), lr=1e-2, momentum=0.9), CrossEntropyLoss()
+
+    g = torch.Generator("cpu").manual_seed(0)
+    data = [(torch.randn(64, 3, 32, 32, generator=g).cuda(), torch.randint(0, 10, (64,), generator=g).cuda()) for _ in range(4)]
+    m, eng, opt, crit = make()
+    eager = []
+    for x, y in [data[0]] + data:                     # one warm-up batch, as the graphed run takes
+        opt.zero_grad(); loss = crit(m(x), y); loss.backward(); opt.step()
+        eager.append(loss.item())
+    p_eager = eng.pack.flat.clone()
+    n_buckets = len(eng.reducer.launched) // 5
+    assert n_buckets >= 2
+
+    m2, eng2, opt2, crit2 = make()
+    step = GraphedStep(m2, crit2, opt2, *data[0], warmup=1)
+    launched_at_capture = len(eng2.reducer.launched)
+    assert launched_at_capture == 2 * n_buckets       # warm-up + capture pass each queued every bucket
+    # the capture pass ran on the first batch without executing: restart from the state after the warm-up step
+    graphed = [step.warm_loss.item()] + [step(x, y).item() for x, y in data]
+    assert len(eng2.reducer.launched) == launched_at_capture, "replays must not go through Python's reducer again"
+    assert graphed == pytest.approx(eager, rel=1e-5, abs=1e-6), (graphed, eager)
+    torch.testing.assert_close(eng2.pack.flat, p_eager, rtol=1e-5, atol=1e-6)
+
+
 # ---- two ranks on ONE GPU over gloo: the real multi-rank logic (parameter broadcast, bucket
 # spans, SUM + grad_scale = mean) through the HIP engine and its two-stream backward.
 def _two_rank_worker(rank, world, port, compute, outdir):
@@ -159,3 +196,10 @@ def test_bench_launches_itself_and_runs_the_rccl_path_end_to_end():
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0
     assert d["config"]["parallelism"] == "dp1" and d["config"]["hip_graph"] is False
+    # the same launcher with the exchange captured inside the HIP graph (--graph on under DDP)
+    code2 = code.replace("'--graph', 'off'", "'--graph', 'on'")
+    assert code2 != code
+    r2 = subprocess.run([sys.executable, "-c", code2], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    d2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
+    assert d2["config"]["hip_graph"] is True and d2["value"] > d["value"], (d2["value"], d["value"])

@@ -391,8 +391,8 @@ def swin_tiny_model(compute):
 
 
 ZERO_GRAD = ("proj_l.bias", "attn.k.bias")      # analytically zero gradients (softmax shift invariance)
-BF16_COS_FULL = 0.995     # the same over 256 sampled entries of a full-size (12-26 block) model; printed by the test
-BF16_COS = 0.999          # per-parameter cosine of bf16-mode gradients with the fp32 reference's (measured >= 0.9995)
+BF16_COS_FULL = 0.998     # the same over 256 sampled entries of a full-size (12-26 block) model; printed by the test
+BF16_COS = 0.9998         # per-parameter cosine of bf16-mode gradients with the fp32 reference's (measured 0.99996; sampled full-size 0.9993 on pos_embed of ViT-B/16, >= 0.9999 elsewhere)
 
 
 @pytest.mark.parametrize("fam,compute", [("cait", "fp32"), ("swin", "fp32"), ("cait", "bf16"), ("swin", "bf16")])

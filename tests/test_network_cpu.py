@@ -72,3 +72,24 @@ def test_bench_parent_launches_ranks_without_touching_the_gpu(monkeypatch):
     i = cmd.index(bench.__file__ if bench.__file__ in cmd else [c for c in cmd if c.endswith("bench.py")][0])
     assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
     assert calls["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_bench_refuses_a_traffic_file_from_other_kernel_sources(tmp_path):
+    """`roofline.traffic` comes from a committed PMC file; bench.py must quote it only when
+    the file's kernel-source fingerprint equals that of the sources it runs (tools/pmc_traffic.py records it)."""
+    import hashlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    csrc = os.path.join(root, "vit_torch_amd", "csrc")
+    h = hashlib.sha256()
+    for fn in sorted(os.listdir(csrc)):
+        if fn.endswith((".hip", ".h", ".cpp")):
+            h.update(fn.encode()); h.update(open(os.path.join(csrc, fn), "rb").read())
+    assert bench.kernel_sources_sha256() == h.hexdigest()
+    src = open(os.path.join(root, "bench.py")).read()
+    assert 'meta.get("kernel_sources_sha256") != kernel_sources_sha256()' in src and "refused, traffic = null" in src
+    tool = open(os.path.join(root, "tools", "pmc_traffic.py")).read()
+    assert "kernel_sources_sha256" in tool

@@ -20,7 +20,7 @@ from util import assert_close, grad_agreement
 pytestmark = pytest.mark.gpu
 
 BF16_LOGITS, BF16_LOSS, BF16_GRADNORM = 1.5e-2, 1e-2, 8e-3
-BF16_COS = 0.995            # worst per-parameter gradient cosine, bf16 mode vs the fp32 oracle (printed by the test)
+BF16_COS = 0.9995           # worst per-parameter gradient cosine, bf16 mode vs the fp32 oracle (printed by the test)
 
 
 def data(B, S, seed=0):

@@ -6,7 +6,8 @@ trained for 50 steps of the harness sequence zero_grad -> backward -> SGD(moment
 seeded weights: the fp32 oracle on the CPU, the HIP path with bf16 operands + fp32 residual stream, and the
 HIP path with bf16 operands + bf16 residual stream (the benchmarked mode).  The loss curves of both HIP
 runs must stay within a stated gap of the oracle's, and the bf16 stream must not be materially further from
-the oracle than the fp32 stream is.  Bounds = ~2x the gaps measured on the MI355X (printed)."""
+the oracle than the fp32 stream is.  Bounds = ~2x the gaps measured on the MI355X (printed; round 3: oracle loss
+2.258 -> 0.818; fp32 stream max gap 0.018, final 0.06 %; bf16 stream max gap 0.020, final 1.1 %)."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -14,8 +15,8 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 STEPS, NB, B, IMG, LR = 50, 4, 16, 64, 0.02
-MAX_GAP = 0.03            # max_t |loss_hip(t) - loss_oracle(t)|, both residual-stream dtypes
-FINAL_REL = 0.05          # |loss_hip - loss_oracle| / loss_oracle at the last step
+MAX_GAP = 0.04            # max_t |loss_hip(t) - loss_oracle(t)|, both residual-stream dtypes
+FINAL_REL = 0.025         # |loss_hip - loss_oracle| / loss_oracle at the last step
 
 
 def batches():

@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 BF16_TOL = {"fp32": (1.2e-2, 1e-2, 8e-3), "bf16": (2e-2, 1e-2, 8e-3)}
 # worst per-parameter cosine between bf16-mode gradients and the fp32 oracle's (small 2-block model / full ViT-B/16);
 # the tests print the measured value
-BF16_COS, BF16_COS_FULL = 0.999, 0.995
+BF16_COS, BF16_COS_FULL = 0.9998, 0.9995        # measured 0.99996 / 0.99991 (round 3)
 
 
 def make_pair(cfg, classifier, compute, residual="fp32", seed=1):

@@ -34,6 +34,14 @@ for k in sorted(fetch, key=lambda k: -(2 * fetch[k] + write.get(k, 0))):
 # steps profiled = launches of the once-per-step optimizer kernel (lets a reader turn
 # per-launch bytes into per-step bytes when one GEMM call is several launches)
 steps = [v["launches"] for k, v in out.items() if k.startswith("sgd_momentum_kernel")]
-out["_meta"] = {"steps_profiled": steps[0] if steps else None}
+# fingerprint of the kernel sources the counters were collected on: bench.py quotes `traffic` only from a file whose
+# fingerprint equals that of the sources it runs (a stale file is refused, not quoted)
+import hashlib, os
+csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vit_torch_amd", "csrc")
+h = hashlib.sha256()
+for fn in sorted(os.listdir(csrc)):
+    if fn.endswith((".hip", ".h", ".cpp")):
+        h.update(fn.encode()); h.update(open(os.path.join(csrc, fn), "rb").read())
+out["_meta"] = {"steps_profiled": steps[0] if steps else None, "kernel_sources_sha256": h.hexdigest()}
 if len(sys.argv) > 3:
     json.dump(out, open(sys.argv[3], "w"), indent=1)

@@ -95,6 +95,8 @@ SIGNATURES = {
     "vitmi_sgd_momentum": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_vp]),
     "vitmi_image_ingest": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
                                      c_i64, c_vp]),
+    "vitmi_ingest_patchify": (C.c_int, [c_vp, c_vp, C.c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64,
+                                        c_i64, c_i64, c_i64, c_i64, C.c_int, c_vp]),
     "vitmi_adam": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, C.c_int,
                              c_f32, c_vp]),
     "vitmi_adagrad": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp]),

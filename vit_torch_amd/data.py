@@ -7,6 +7,11 @@ The reference transforms every sample on CPU DataLoader workers
 NCHW tensor in one kernel; the per-sample crop offsets and flip flags are drawn with a torch
 generator (pass them explicitly to pin a batch).  Resize (bicubic, only when the requested
 size differs from the stored one) is not part of this kernel.
+
+`DeviceAugment.patch_rows(images, patch_size, dtype)` goes one step further (round 3): the same
+transform written straight into the patch rows the patch-embedding GEMM contracts
+(`vitmi_ingest_patchify`: uint8 NHWC -> bf16 patch rows in one pass, no fp32 NCHW intermediate); the
+returned `PatchRows` is accepted by `VisionTransformer.forward` in place of the image tensor.
 """
 from __future__ import annotations
 
@@ -50,3 +55,28 @@ class DeviceAugment:
             off_y, off_x, flip = self.draw(B, H, W)
         out = torch.empty((B, C, self.S, self.S), dtype=torch.float32, device=x.device)
         return ops.image_ingest(x.contiguous(), out, off_y, off_x, flip, self.mean, self.std, self.pad)
+
+    def patch_rows(self, images_u8_nhwc, patch_size: int, dtype=torch.bfloat16, cls_rows: int = 1,
+                   off_y=None, off_x=None, flip=None) -> "PatchRows":
+        x = images_u8_nhwc
+        if not x.is_cuda:
+            x = x.to(self.device, non_blocking=True)
+        B, H, W, C = x.shape
+        if self.train and off_y is None:
+            off_y, off_x, flip = self.draw(B, H, W)
+        g = self.S // patch_size
+        rows = torch.empty((B * (cls_rows + g * g), C * patch_size * patch_size), dtype=dtype, device=x.device)
+        ops.ingest_patchify(x.contiguous(), rows, off_y, off_x, flip, self.mean, self.std, self.S, self.pad, patch_size,
+                            cls_rows)
+        return PatchRows(rows, B, C, self.S, self.S, patch_size, cls_rows)
+
+
+class PatchRows:
+    """A batch already in patch-row form ([B*(cls_rows + gh*gw), C*p*p], the GEMM operand dtype): what
+    `VisionTransformer.forward` takes instead of an fp32 [B,C,H,W] tensor when the input pipeline runs on
+    the device (the engine then skips its own patch gather)."""
+    is_cuda = True
+
+    def __init__(self, rows, B, C, H, W, p, cls_rows):
+        self.rows, self.B, self.C, self.H, self.W, self.p, self.cls_rows = rows, B, C, H, W, p, cls_rows
+        self.device = rows.device

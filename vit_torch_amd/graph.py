@@ -16,8 +16,14 @@ inside a capture, so at least one is needed the first time).  `warm_out` / `warm
 the last warm-up step's logits and loss, for callers that account for that batch.
 Limits (checked or documented): parameters must only be changed by the captured optimizer
 between replays (re-capture after load_state_dict or a learning-rate change: the LR is a
-kernel argument baked into the graph; `step.recapture()`), single process (the RCCL
-exchange is not captured: use the eager step with GradReducer for data parallelism).
+kernel argument baked into the graph; `step.recapture()`).
+
+Data parallelism: an engine with a `ddp.GradReducer` is captured WITH its gradient exchange —
+ProcessGroupNCCL's collectives are capturable (the bucket all-reduces become nodes on RCCL's
+stream inside the graph, joined to the compute stream by the events `Work.wait()` records), so
+launch-bound configurations (dino_vits16 at 32x32: 9.5 ms eager, 3.7 ms replayed) keep the graph
+at N > 1.  The warm-up steps run the exchange eagerly first (the communicator must exist before
+a capture starts); every rank must capture and replay the same number of times.
 """
 from __future__ import annotations
 
@@ -31,8 +37,10 @@ class GraphedStep:
         if not x_example.is_cuda:
             raise VitmiError("GraphedStep needs example inputs on the GPU")
         eng = model.engine() if hasattr(model, "engine") else None
-        if eng is not None and getattr(eng, "reducer", None) is not None:
-            raise VitmiError("GraphedStep does not capture the RCCL gradient exchange; use the eager step")
+        red = getattr(eng, "reducer", None) if eng is not None else None
+        if red is not None and warmup < 1:
+            raise VitmiError("GraphedStep with a GradReducer needs warmup >= 1: the RCCL communicator must be "
+                             "created by an eager exchange before the capture starts")
         self.model, self.criterion, self.optimizer = model, criterion, optimizer
         self.x = x_example.detach().clone()
         self.y = y_example.detach().clone()

@@ -301,6 +301,21 @@ def image_ingest(src, dst, off_y, off_x, flip, mean, std, pad, fill=128):
     return dst
 
 
+def ingest_patchify(src, out, off_y, off_x, flip, mean, std, S, pad, p, cls_rows, fill=128):
+    """src uint8 [B,H,W,C] (NHWC) -> out [B*(cls_rows + (S/p)^2), ld >= C*p*p] patch rows; see vitmi_ingest_patchify."""
+    _need_cuda(src, out)
+    assert src.dtype == torch.uint8 and src.is_contiguous() and out.dim() == 2 and out.is_contiguous()
+    B, H, W, C = src.shape
+    g = S // p
+    assert out.shape[0] == B * (cls_rows + g * g) and out.shape[1] >= C * p * p
+    for t, dt in ((off_y, torch.int32), (off_x, torch.int32), (flip, torch.uint8), (mean, torch.float32), (std, torch.float32)):
+        assert t is None or (t.is_cuda and t.dtype == dt and t.is_contiguous())
+    check(load().vitmi_ingest_patchify(src.data_ptr(), out.data_ptr(), dtype_code(out), out.shape[1], _ptr(off_y), _ptr(off_x),
+                                       _ptr(flip), _ptr(mean), _ptr(std), B, H, W, C, int(S), int(pad), int(fill), int(p),
+                                       int(cls_rows), _stream()), "vitmi_ingest_patchify")
+    return out
+
+
 def adam(p, g, m, v, shadow, state, lr, beta1, beta2, eps, weight_decay, decoupled, grad_scale=1.0):
     _need_cuda(p, g, m, v, state)
     assert p.dtype == g.dtype == m.dtype == v.dtype == state.dtype == torch.float32
