@@ -163,6 +163,45 @@ def kernel_sources_sha256():
     return h.hexdigest()
 
 
+def clock_under_load(rows):
+    """Shader clock the chip holds under the step's GEMM kernels: one stamped launch per (layout, M, N, K) of the
+    instrumented step (every workgroup records s_memtime / s_memrealtime at entry and exit: clock = cycles / wall, median
+    over workgroups — the in-kernel method of the guide's DVFS section; tools/clock_check.sh cross-checks it against
+    GRBM_GUI_ACTIVE / 8 / wall on >= 10 ms dispatches), averaged with each shape's share of the GEMM time."""
+    import ctypes
+    import numpy as np
+    from vit_torch_amd import _lib, ops
+    raw = ctypes.CDLL(str(_lib.LIB_PATH))
+    raw.vitmi_debug_gemm_timeline.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    per, wsum, csum = {}, 0.0, 0.0
+    for (name, (M, N, K)), (cnt, _flops, secs) in sorted(rows.items()):
+        if (M % 256) or (N % 256) or (K % 64):
+            continue
+        akm, bkm = name[5] == "n", name[6] == "t"
+        A = torch.randn((M, K) if akm else (K, M), device="cuda").to(torch.bfloat16)
+        B = (torch.randn((N, K) if bkm else (K, N), device="cuda") * 0.05).to(torch.bfloat16)
+        C = torch.empty((M, N), device="cuda", dtype=torch.bfloat16 if akm else torch.float32)
+        for _ in range(3):
+            ops.gemm(A, B, C, a_kmajor=akm, b_kmajor=bkm)
+        nb = 512
+        buf = torch.zeros(64 + 8 * nb, dtype=torch.int64, device="cuda")
+        raw.vitmi_debug_gemm_timeline(buf.data_ptr(), nb)
+        ops.gemm(A, B, C, a_kmajor=akm, b_kmajor=bkm)
+        torch.cuda.synchronize()
+        raw.vitmi_debug_gemm_timeline(None, 64)
+        t = buf.cpu().numpy()[64:].reshape(nb, 8).astype(np.float64)
+        ok = (t[:, 6] > t[:, 4]) & (t[:, 5] > t[:, 0])
+        if not ok.any():
+            continue
+        mhz = float(np.median((t[ok, 5] - t[ok, 0]) / ((t[ok, 6] - t[ok, 4]) * 10.0))) * 1e3
+        per[f"{name}:{M}x{N}x{K}"] = round(mhz, 1)
+        wsum += secs
+        csum += secs * mhz
+        del A, B, C
+    torch.cuda.empty_cache()
+    return (round(csum / wsum, 1) if wsum else None), per
+
+
 def self_launch(n):
     """Parent of a multi-GPU run started as plain `python bench.py --gpus N`: spawn one rank per
     GPU through torch.distributed.run and relay their output.  Nothing in this process has
@@ -404,6 +443,10 @@ def main():
                                 f"command in {traffic_file}, whose kernel-source fingerprint matches this build")
         except Exception:
             pass
+        try:
+            clock_mhz, clock_by_shape = clock_under_load(rows)
+        except Exception as e:      # a diagnostic: never fails the measurement
+            clock_mhz, clock_by_shape = None, {"error": f"{type(e).__name__}: {e}"}
         roof = {"bound": "mfma", "kernel": "gemm_fast_kernel (all GEMM launches of one step)",
                 "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
@@ -411,6 +454,11 @@ def main():
                 "flop_per_launch": round(tot_f / n_launch),
                 "launches_per_step": n_launch, "avg_launch_ms": round(tot_t / n_launch * 1e3, 4),
                 "gemm_ms_per_step": round(tot_t * 1e3, 3),
+                "clock_mhz_under_load": clock_mhz, "clock_mhz_by_shape": clock_by_shape,
+                "clock_note": ("in-kernel s_memtime / s_memrealtime of one stamped launch per GEMM shape, weighted by the shape's "
+                               "share of the GEMM time; `peak` assumes 2400 MHz.  achieved / (peak x clock / 2400) = "
+                               f"{round(ach / (PEAK_BF16_TFLOPS * clock_mhz / 2400.0), 4) if clock_mhz else None} of what the "
+                               "matrix pipes can issue at the clock actually held (the MFMA-busy fraction of the GEMM time)"),
                 "by_shape": [{"kernel": k[0], "MNK": list(k[1]), "launches": v[0],
                               "avg_ms": round(v[2] / v[0] * 1e3, 4),
                               "tflops": round(v[1] / v[2] / 1e12, 1)} for k, v in sorted(rows.items())]}
