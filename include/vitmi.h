@@ -133,6 +133,17 @@ typedef struct vitmi_gemm_desc {
 } vitmi_gemm_desc;
 
 int vitmi_gemm(const vitmi_gemm_desc* d, void* stream);
+/* Two products in ONE launch: C0 = op(A0) op(B0)^T and C1 = op(A1) op(B1)^T.  Meant for the two weight gradients of an
+ * attention block (dW_proj = dY^T x: 768 x 768, and dW_qkv: 2304 x 768; autograd of models/swin.py:119-144): both contract
+ * over all tokens, and the small one alone has too few output tiles to fill the chip without cutting K into 28 slices.
+ * Sharing a grid, the 9 + 27 tiles take 7 slices each (a quarter of the partial-tile traffic, one pipeline fill per 113
+ * k-steps instead of 29).  Pairable: bf16 operands, both k-minor (a_kmajor = b_kmajor = 0), fp32 C, EPI_STORE without bias /
+ * accumulate, the same K, whole 256 x 256 x 64 tiles, `workspace` >= vitmi_gemm_pair_workspace (the descriptors' own
+ * workspace fields are used only by the fallback).  Anything else runs as two vitmi_gemm calls: same results either way
+ * (the split-K reduction sums the slices in a fixed order). */
+size_t vitmi_gemm_pair_workspace(const vitmi_gemm_desc* d0, const vitmi_gemm_desc* d1);
+int vitmi_gemm_pair(const vitmi_gemm_desc* d0, const vitmi_gemm_desc* d1, void* workspace, size_t workspace_bytes,
+                    void* stream);
 /* bytes of scratch that let the fast kernel split the contraction over more
  * workgroups (weight gradients: few output tiles, K = all tokens); 0 if none */
 size_t vitmi_gemm_workspace(const vitmi_gemm_desc* d);

@@ -839,3 +839,35 @@ def test_attention_bwd_persistent_pair_walk(ops, lib):
     o_ref.backward(do)
     assert_close("dqkv", outs[0][0], qr.grad, 2.5e-2)
     assert_close("dbias", outs[0][1].sum(0), qr.grad.view(B * N, -1).sum(0), 2.5e-2)
+
+
+def test_gemm_pair_shares_one_split_k_launch(ops, lib):
+    """vitmi_gemm_pair: the proj (768 x 768) and qkv (2304 x 768) weight gradients of an attention block in one grid
+    (36 tiles x 7 k-slices instead of 9 x 28 + 27 x 9).  Must agree with the fp64 reference and with the two
+    separate launches (summation order over k-slices differs: fp32 rounding only); unpairable inputs fall back."""
+    K, D = 197 * 64, 768                       # 12 608 tokens: a multiple of 64, ragged against the slice length
+    g = torch.Generator("cpu").manual_seed(91)
+    bt = torch.bfloat16
+    dy0, x0 = bf16_round(torch.randn(K, D, generator=g)), bf16_round(torch.randn(K, D, generator=g))
+    dy1, x1 = bf16_round(torch.randn(K, 3 * D, generator=g)), bf16_round(torch.randn(K, D, generator=g))
+    DY0, X0, DY1, X1 = dev(dy0, bt), dev(x0, bt), dev(dy1, bt), dev(x1, bt)
+    assert ops.gemm_pair_shares_a_launch(D, D, 3 * D, D, K)
+    W0 = torch.full((D, D), float("nan"), device="cuda")
+    W1 = torch.full((3 * D, D), float("nan"), device="cuda")
+    ops.gemm_pair(DY0, X0, W0, DY1, X1, W1)
+    S0, S1 = torch.empty_like(W0), torch.empty_like(W1)
+    ops.gemm(DY0, X0, S0, a_kmajor=False, b_kmajor=False)
+    ops.gemm(DY1, X1, S1, a_kmajor=False, b_kmajor=False)
+    want0, want1 = (dy0.double().t() @ x0.double()).float(), (dy1.double().t() @ x1.double()).float()
+    assert_close("pair dW0", W0, want0, 2e-5)
+    assert_close("pair dW1", W1, want1, 2e-5)
+    assert_close("pair vs separate dW0", W0, S0.cpu(), 2e-5)
+    assert_close("pair vs separate dW1", W1, S1.cpu(), 2e-5)
+    # not pairable (ragged N): falls back to two launches with the same results
+    dy2 = bf16_round(torch.randn(K, 200, generator=g))
+    assert not ops.gemm_pair_shares_a_launch(D, D, 200, D, K)
+    W2 = torch.full((200, D), float("nan"), device="cuda")
+    W0b = torch.full((D, D), float("nan"), device="cuda")
+    ops.gemm_pair(DY0, X0, W0b, dev(dy2, bt), X1, W2)
+    assert torch.equal(W0b, S0)
+    assert_close("fallback dW2", W2, (dy2.double().t() @ x1.double()).float(), 2e-5)

@@ -19,6 +19,17 @@ raw.vitmi_debug_gemm_tail(0)
 scale = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 EPI = {"store": _lib.EPI_STORE, "gelu": _lib.EPI_BIAS_GELU, "res": _lib.EPI_RESIDUAL, "dgelu": _lib.EPI_DGELU}
 SHAPES = ["nt:50432:3072:768:gelu", "nt:50432:2304:768", "nn:50432:3072:768:dgelu", "nn:50432:768:3072", "nt:50432:768:3072:res"]
+# >= 2 s of back-to-back GEMM launches first: the power management needs that long to settle at the clock it holds
+# under sustained load (the first dispatches of a cold process ran 30 % faster than the steady state)
+_A = torch.randn(8192, 8192, device="cuda").to(torch.bfloat16)
+_C = torch.empty(8192, 8192, device="cuda", dtype=torch.bfloat16)
+import time
+_t = time.time()
+while time.time() - _t < 2.5:
+    for _ in range(20):
+        ops.gemm(_A, _A, _C)
+    torch.cuda.synchronize()
+del _A, _C
 out = []
 for spec in SHAPES:
     parts = spec.split(":")

@@ -53,6 +53,8 @@ SIGNATURES = {
     "vitmi_version": (C.c_int, []),
     "vitmi_last_error_string": (C.c_char_p, []),
     "vitmi_gemm": (C.c_int, [C.POINTER(GemmDesc), c_vp]),
+    "vitmi_gemm_pair_workspace": (c_sz, [C.POINTER(GemmDesc), C.POINTER(GemmDesc)]),
+    "vitmi_gemm_pair": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(GemmDesc), c_vp, c_sz, c_vp]),
     "vitmi_gemm_uses_fast": (C.c_int, [C.POINTER(GemmDesc)]),
     "vitmi_gemm_workspace": (c_sz, [C.POINTER(GemmDesc)]),
     "vitmi_layernorm_fwd": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, c_vp, c_vp, C.c_int, c_i64,

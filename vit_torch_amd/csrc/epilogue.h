@@ -33,6 +33,9 @@ struct GemmArgs {
   int rfold;                      // gemm_fast: stream the fp32 residual through LDS during the main loop
   int band;                       // gemm_fast: column-band width of the tile order (0 = row-major)
   int launch_flags;               // VITMI_LAUNCH_*
+  // gemm_fast split-K, PAIRED launch (vitmi_gemm_pair): a second product with the same K / layouts shares the grid;
+  // tiles [0, tiles1) belong to this problem, [tiles1, tiles1 + tiles2) to the second one (tiles1 == 0: no pair)
+  const void* A2; const void* B2; int64_t lda2, ldb2, M2, N2; int tiles1, tiles_n2; float* ws2;
   int stag_cycles, stag_phases;   // gemm_fast, persistent walk: start delay of the workgroups with the shorter tile list
   EpiArgs e;
 };

@@ -185,6 +185,7 @@ static int build_args(const vitmi_gemm_desc* d, GemmArgs* out) {
   g.band = 0;
   g.stag_cycles = 0; g.stag_phases = 1;
   g.launch_flags = d->launch_flags;
+  g.A2 = g.B2 = nullptr; g.lda2 = g.ldb2 = g.M2 = g.N2 = 0; g.tiles1 = g.tiles_n2 = 0; g.ws2 = nullptr;
   g.dbg = g_gemm_dbg;
   g.dbg_blocks = g_gemm_dbg_blocks;
   g.batch = d->batch > 1 ? d->batch : 1;
@@ -269,6 +270,34 @@ extern "C" size_t vitmi_gemm_workspace(const vitmi_gemm_desc* d) {
   if (build_args(d, &g) != 0 || d->impl == VITMI_GEMM_GENERIC) return 0;
   if (g.batch > 1 || !gemm_fast_supported(g, d->in_dtype == VITMI_BF16)) return 0;
   return gemm_fast_workspace(g);
+}
+
+size_t gemm_fast_pair_workspace(const GemmArgs& a, const GemmArgs& b);
+int gemm_fast_pair_launch(const GemmArgs& a, const GemmArgs& b, void* ws, size_t ws_bytes, hipStream_t stream);
+
+static int g_pair = 1;               // diagnostic hook: 0 = never pair (two launches), for A/B inside the step
+extern "C" void vitmi_debug_gemm_pair(int on) { g_pair = on != 0; }
+static bool pair_args(const vitmi_gemm_desc* d0, const vitmi_gemm_desc* d1, GemmArgs* a, GemmArgs* b) {
+  if (!g_pair) return false;
+  if (build_args(d0, a) != 0 || build_args(d1, b) != 0) return false;
+  if (d0->in_dtype != VITMI_BF16 || d1->in_dtype != VITMI_BF16) return false;
+  if (d0->impl == VITMI_GEMM_GENERIC || d1->impl == VITMI_GEMM_GENERIC) return false;
+  return gemm_fast_supported(*a, true) && gemm_fast_supported(*b, true);
+}
+extern "C" size_t vitmi_gemm_pair_workspace(const vitmi_gemm_desc* d0, const vitmi_gemm_desc* d1) {
+  GemmArgs a, b;
+  if (!pair_args(d0, d1, &a, &b)) return 0;
+  return gemm_fast_pair_workspace(a, b);
+}
+extern "C" int vitmi_gemm_pair(const vitmi_gemm_desc* d0, const vitmi_gemm_desc* d1, void* workspace, size_t workspace_bytes,
+                               void* stream_) {
+  GemmArgs a, b;
+  if (pair_args(d0, d1, &a, &b)) {
+    const int rc = gemm_fast_pair_launch(a, b, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream_));
+    if (rc != -1000) return rc;
+  }
+  if (int rc = vitmi_gemm(d0, stream_)) return rc;      // not pairable: one after the other, same results
+  return vitmi_gemm(d1, stream_);
 }
 
 extern "C" int vitmi_gemm(const vitmi_gemm_desc* d, void* stream_) {

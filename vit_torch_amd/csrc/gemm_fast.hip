@@ -339,8 +339,21 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
   const int wg0 = x_start + slot;
   const int split = SPLITK ? wg0 / ntiles : 0;
 
+  // the problem this workgroup works on: the descriptor's, or (paired split-K launch) the second one
   const bf16* A = reinterpret_cast<const bf16*>(g.A);
   const bf16* B = reinterpret_cast<const bf16*>(g.B);
+  int64_t lda = g.lda, ldb = g.ldb, pM = g.M, pN = g.N;
+  int idx = slot;                                  // position inside the XCD's run (PERSIST)
+  int tile = tile0 + (SPLITK ? wg0 % ntiles : x_start + idx);
+  if constexpr (SPLITK) {
+    if (g.tiles1 > 0 && tile >= g.tiles1) {        // wave-uniform
+      tile -= g.tiles1;
+      A = reinterpret_cast<const bf16*>(g.A2); B = reinterpret_cast<const bf16*>(g.B2);
+      lda = g.lda2; ldb = g.ldb2; pM = g.M2; pN = g.N2;
+      tiles_n = g.tiles_n2;
+      ws = g.ws2;
+    }
+  }
   const int nt_all = (int)(g.K / BK);
   const int kt0 = SPLITK ? split * ksps : 0;
   const int nt = SPLITK ? min(ksps, nt_all - kt0) : nt_all;
@@ -392,8 +405,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
   // plans of a tile + the DMAs that precede its main loop
   auto start_tile = [&](int64_t m0, int64_t n0) {
     if constexpr (RINGP) {
-      sa.init(A, g.lda, m0, kb0, wave, lane);
-      sb.init(B, g.ldb, n0, kb0, wave, lane);
+      sa.init(A, lda, m0, kb0, wave, lane);
+      sb.init(B, ldb, n0, kb0, wave, lane);
       if constexpr (RFOLD_T) { if (rfold) rf.init(reinterpret_cast<const float*>(g.e.R), g.e.ldr, m0, n0, wm, wn, lane); }
 #pragma unroll
       for (int a = 0; a < AHEAD; ++a)
@@ -404,8 +417,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
         }
       if constexpr (RFOLD_T) { if (rfold) rf.issue(rstrip, 0); }     // strip 0 rides behind the prologue slabs
     } else if constexpr (PIPE == 2) {
-      ta.init(A, g.lda, m0, kb0, wave, lane);
-      tb.init(B, g.ldb, n0, kb0, wave, lane);
+      ta.init(A, lda, m0, kb0, wave, lane);
+      tb.init(B, ldb, n0, kb0, wave, lane);
       ta.issue(smem, 0, wave);
       tb.issue(smem + TILE_BYTES, 0, wave);
       if (nt > 1) {
@@ -413,15 +426,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
         tb.issue(smem + STAGE_BYTES + TILE_BYTES, 1, wave);
       }
     } else {                       // PIPE 0: stage 0 (the loop issues stage t + 1 itself)
-      stage_tile<A_KM>(smem, A, g.lda, m0, kb0, wave, lane);
-      stage_tile<B_KM>(smem + TILE_BYTES, B, g.ldb, n0, kb0, wave, lane);
+      stage_tile<A_KM>(smem, A, lda, m0, kb0, wave, lane);
+      stage_tile<B_KM>(smem + TILE_BYTES, B, ldb, n0, kb0, wave, lane);
     }
   };
 
-  int idx = slot;                                  // position inside the XCD's run (PERSIST)
-  int tile = tile0 + (SPLITK ? wg0 % ntiles : x_start + idx);
   if (PERSIST && idx >= x_len) return;
-  const int tiles_m = (int)(g.M / BM);
+  const int tiles_m = (int)(pM / BM);
   int mt_, nt_;
   tile_mn(tile, tiles_m, tiles_n, g.band, &mt_, &nt_);
   int64_t m0 = (int64_t)mt_ * BM, n0 = (int64_t)nt_ * BN;
@@ -457,8 +468,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
     char* cur = smem + (t & 1) * STAGE_BYTES;
     if (t + 1 < nt) {
       char* nxt = smem + ((t + 1) & 1) * STAGE_BYTES;
-      stage_tile<A_KM>(nxt, A, g.lda, m0, (int64_t)(kt0 + t + 1) * BK, wave, lane);
-      stage_tile<B_KM>(nxt + TILE_BYTES, B, g.ldb, n0, (int64_t)(kt0 + t + 1) * BK, wave, lane);
+      stage_tile<A_KM>(nxt, A, lda, m0, (int64_t)(kt0 + t + 1) * BK, wave, lane);
+      stage_tile<B_KM>(nxt + TILE_BYTES, B, ldb, n0, (int64_t)(kt0 + t + 1) * BK, wave, lane);
     }
     const char* At = cur;
     const char* Bt = cur + TILE_BYTES;
@@ -704,7 +715,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
         v[4 * qq] = t4[0]; v[4 * qq + 1] = t4[1]; v[4 * qq + 2] = t4[2]; v[4 * qq + 3] = t4[3];
       }
       if constexpr (SPLITK)
-        storev<float, W>(ws + row_off((int64_t)split * g.M + m0 + wm * 128 + mi * 16 + j * RPI, rr, g.N, ncol), v);
+        storev<float, W>(ws + row_off((int64_t)split * pM + m0 + wm * 128 + mi * 16 + j * RPI, rr, pN, ncol), v);
       else {
         epi_row<MODE, TC, W>(g.e, m0 + wm * 128 + mi * 16 + j * RPI, rr, ncol, v, bias_r, gamma_r, sx[mi & 1][j]);
         if constexpr (MODE == VITMI_EPI_DGELU) {
@@ -1091,6 +1102,55 @@ static int gemm_fast_launch_whole(const GemmArgs& g, hipStream_t s) {
   }
 #undef GO
   return vitmi_fail(VITMI_E_SHAPE, "gemm_fast: combination not built");
+}
+
+// ---- paired split-K launch (vitmi_gemm_pair): two weight-gradient products dW = dY^T X with the same K (all
+// tokens) and layouts share ONE grid.  Why: the 768 x 768 proj gradient has 9 output tiles, so alone it is cut
+// into 28 k-slices of 29 k-steps (each workgroup pays a pipeline fill and a 256-KB partial tile for 29 steps,
+// 66 MB of partials in all: 789 TFLOP/s against 1 085-1 150 on the wider gradients); beside the 27 tiles of the
+// qkv gradient the 36 tiles take 7 slices of 113 steps each and a quarter of the partial traffic.
+static bool pair_ok(const GemmArgs& a, const GemmArgs& b) {
+  auto plain = [](const GemmArgs& g) {
+    return !g.a_km && !g.b_km && g.e.mode == VITMI_EPI_STORE && !g.e.c_bf16 && !g.e.bias && !g.e.accumulate &&
+           g.e.alpha == 1.f && g.batch == 1 && (g.M % BM) == 0 && (g.N % BN) == 0 && (g.K % BK) == 0;
+  };
+  return plain(a) && plain(b) && a.K == b.K;
+}
+size_t gemm_fast_pair_workspace(const GemmArgs& a, const GemmArgs& b) {
+  if (!pair_ok(a, b)) return 0;
+  const int tiles = (int)(a.M / BM * (a.N / BN) + b.M / BM * (b.N / BN));
+  int splits, ksps;
+  splitk_plan(tiles, (int)(a.K / BK), &splits, &ksps);
+  if (splits <= 1) return 0;
+  return (size_t)splits * (a.M * a.N + b.M * b.N) * sizeof(float);
+}
+// returns -1000 when the pair cannot share a launch (the caller then issues the two products one after the other)
+int gemm_fast_pair_launch(const GemmArgs& a_in, const GemmArgs& b, void* ws_, size_t ws_bytes, hipStream_t stream) {
+  const size_t need = gemm_fast_pair_workspace(a_in, b);
+  if (need == 0 || !ws_ || ws_bytes < need || !is_aligned(ws_, 16) || pipe_mode() == 0 || pipe_mode() == 2) return -1000;
+  GemmArgs g = a_in;
+  const int t1 = (int)(g.M / BM * (g.N / BN)), t2 = (int)(b.M / BM * (b.N / BN));
+  int splits, ksps;
+  splitk_plan(t1 + t2, (int)(g.K / BK), &splits, &ksps);
+  float* ws = reinterpret_cast<float*>(ws_);
+  g.A2 = b.A; g.B2 = b.B; g.lda2 = b.lda; g.ldb2 = b.ldb; g.M2 = b.M; g.N2 = b.N;
+  g.tiles1 = t1; g.tiles_n2 = (int)(b.N / BN);
+  g.ws2 = ws + (size_t)splits * g.M * g.N;
+  g.band = 0; g.stag_cycles = 0; g.stag_phases = 1; g.rfold = 0;
+  auto kern = gemm_fast_kernel<false, false, VITMI_EPI_STORE, float, true, 1>;
+  if (int rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(kern), 2 * STAGE_BYTES, "gemm_fast(pair)")) return rc;
+  const int nwg = (t1 + t2) * splits;
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(NTHREADS), 2 * STAGE_BYTES, stream, g, (int)(g.N / BN), nwg, t1 + t2, ksps, ws, 0);
+  if (int rc = vitmi_check_launch("gemm_fast_kernel(pair, split-K)")) return rc;
+  for (int i = 0; i < 2; ++i) {
+    const GemmArgs& p = i == 0 ? a_in : b;
+    const int64_t work = p.M * p.N / 4;
+    int64_t blocks = (work + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, i == 0 ? ws : g.ws2, splits, p.e, p.M, p.N);
+    if (int rc = vitmi_check_launch("splitk_reduce_kernel(pair)")) return rc;
+  }
+  return 0;
 }
 
 int gemm_fast_launch(const GemmArgs& g, hipStream_t s) {

@@ -54,6 +54,51 @@ def gemm(A, B, C_out, *, a_kmajor=True, b_kmajor=True, epilogue=EPI_STORE, bias=
          impl=GEMM_AUTO, rowscale=None, rows_per_group=0, colsum_part=None, aux_deriv=False,
          launch_flags=0):
     """C = epilogue(op(A) @ op(B)^T); see vitmi_gemm in include/vitmi.h."""
+    d = _gemm_desc(A, B, C_out, a_kmajor=a_kmajor, b_kmajor=b_kmajor, epilogue=epilogue, bias=bias, R=R, gamma=gamma,
+                   aux=aux, C2=C2, pos=pos, n_tok=n_tok, cls=cls, alpha=alpha, accumulate=accumulate, impl=impl,
+                   rowscale=rowscale, rows_per_group=rows_per_group, colsum_part=colsum_part, aux_deriv=aux_deriv,
+                   launch_flags=launch_flags)
+    lib = load()
+    need = lib.vitmi_gemm_workspace(C.byref(d))
+    if need:
+        ws = workspace(need, A.device)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    check(lib.vitmi_gemm(C.byref(d), _stream()), "vitmi_gemm")
+    return C_out
+
+
+def gemm_pair(A0, B0, C0, A1, B1, C1, launch_flags=0):
+    """Two weight-gradient products C_i = A_i^T @ B_i (k-minor operands [tokens, features], fp32 C) in one launch where
+    the library can pair them (vitmi_gemm_pair), else one after the other; same results."""
+    d0 = _gemm_desc(A0, B0, C0, a_kmajor=False, b_kmajor=False, launch_flags=launch_flags)
+    d1 = _gemm_desc(A1, B1, C1, a_kmajor=False, b_kmajor=False, launch_flags=launch_flags)
+    lib = load()
+    need = max(lib.vitmi_gemm_pair_workspace(C.byref(d0), C.byref(d1)), lib.vitmi_gemm_workspace(C.byref(d0)),
+               lib.vitmi_gemm_workspace(C.byref(d1)))
+    ws = workspace(need, A0.device)
+    for d in (d0, d1):                       # the fallback (two vitmi_gemm calls) splits K through the descriptors' own fields
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    check(lib.vitmi_gemm_pair(C.byref(d0), C.byref(d1), ws.data_ptr(), ws.numel(), _stream()), "vitmi_gemm_pair")
+
+
+def gemm_pair_shares_a_launch(M0, N0, M1, N1, K) -> bool:
+    """Host-only query: would the two k-minor bf16 products [M0,N0] and [M1,N1] over K rows share one launch?"""
+    ds = []
+    for M, N in ((M0, N0), (M1, N1)):
+        d = GemmDesc()
+        d.M, d.N, d.K = M, N, K
+        d.A = d.B = d.C = 256
+        d.lda, d.ldb, d.ldc = M, N, N
+        d.a_kmajor = d.b_kmajor = 0
+        d.in_dtype, d.c_dtype, d.epilogue = BF16, F32, EPI_STORE
+        ds.append(d)
+    return load().vitmi_gemm_pair_workspace(C.byref(ds[0]), C.byref(ds[1])) > 0
+
+
+def _gemm_desc(A, B, C_out, *, a_kmajor=True, b_kmajor=True, epilogue=EPI_STORE, bias=None, R=None,
+               gamma=None, aux=None, C2=None, pos=None, n_tok=0, cls=None, alpha=1.0, accumulate=False,
+               impl=GEMM_AUTO, rowscale=None, rows_per_group=0, colsum_part=None, aux_deriv=False,
+               launch_flags=0):
     _need_cuda(A, B, C_out)
     assert A.dim() == 2 and B.dim() == 2 and C_out.dim() == 2
     assert A.stride(1) == 1 and B.stride(1) == 1 and C_out.stride(1) == 1
@@ -103,13 +148,7 @@ def gemm(A, B, C_out, *, a_kmajor=True, b_kmajor=True, epilogue=EPI_STORE, bias=
         d.colsum_part = colsum_part.data_ptr()
     d.aux_is_derivative = int(bool(aux_deriv))
     d.launch_flags = int(launch_flags)
-    lib = load()
-    need = lib.vitmi_gemm_workspace(C.byref(d))
-    if need:
-        ws = workspace(need, A.device)
-        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
-    check(lib.vitmi_gemm(C.byref(d), _stream()), "vitmi_gemm")
-    return C_out
+    return d
 
 
 def gemm_batched(A, B, C_out, *, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, batch, batch_inner,

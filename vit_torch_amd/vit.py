@@ -189,6 +189,28 @@ def engine_gemm(eng, A, B, C, **k):
     return C
 
 
+def engine_wgrad_pair(eng, dY0, X0, dW0, dY1, X1, dW1):
+    """dW0 = dY0^T X0 and dW1 = dY1^T X1 (the proj and qkv weight gradients of an attention block) in one launch where
+    the library pairs them (ops.gemm_pair / vitmi_gemm_pair), else as two GEMMs."""
+    paired = (eng.gemm_impl == GEMM_AUTO and dY0.dtype == torch.bfloat16 and dW0.dtype == torch.float32
+              and ops.gemm_pair_shares_a_launch(dW0.shape[0], dW0.shape[1], dW1.shape[0], dW1.shape[1], dY0.shape[0]))
+    if not paired:
+        eng._gemm(dY0, X0, dW0, a_kmajor=False, b_kmajor=False)
+        eng._gemm(dY1, X1, dW1, a_kmajor=False, b_kmajor=False)
+        return
+    flags = eng.reducer.launch_flags() if eng.reducer is not None else 0
+    if eng.profile is None:
+        ops.gemm_pair(dY0, X0, dW0, dY1, X1, dW1, launch_flags=flags)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ops.gemm_pair(dY0, X0, dW0, dY1, X1, dW1, launch_flags=flags)
+    e1.record()
+    K = dY0.shape[0]
+    flops = 2.0 * K * (dW0.shape[0] * dW0.shape[1] + dW1.shape[0] * dW1.shape[1])
+    eng.profile.append(("gemm_tn_pair", (dW0.shape[0] + dW1.shape[0], dW0.shape[1], K), flops, e0, e1))
+
+
 def dgelu_gemm_with_bias_grad(eng, Gb, W2, dH, pre, bias_grad):
     """dH = (Gb @ W2) * gelu'(pre) and bias_grad = column sums of dH.  On the bf16 tile paths
     the sums ride on the GEMM epilogue as per-128-row partials (a few MB, folded by colsum);
@@ -457,14 +479,15 @@ class VitEngine:
             # attention branch
             dO = new(M, D, T)
             self._gemm(Gb, self._w(a.proj.weight), dO, b_kmajor=False)
-            self._gemm(Gb, O, pk.g(a.proj.weight), a_kmajor=False, b_kmajor=False)
             dqkv = new(M, 3 * D, T)
             dqkv_part = None
             if fused_bias and a.qkv.bias is not None:
                 dqkv_part = torch.empty((ops.attn_bwd_dbias_rows(B, N), 3 * D), dtype=torch.float32, device=dev)
             ops.attn_bwd(qkv, O, dO, lse, dqkv, B, N, H, hd, a.scale, dbias_part=dqkv_part,
                          launch_flags=self.reducer.launch_flags() if self.reducer is not None else 0)
-            self._gemm(dqkv, ln1, pk.g(a.qkv.weight), a_kmajor=False, b_kmajor=False)
+            # the proj and qkv weight gradients share one split-K launch (Gb still holds this block's G' here: the
+            # LayerNorm backward below is what overwrites it)
+            engine_wgrad_pair(self, Gb, O, pk.g(a.proj.weight), dqkv, ln1, pk.g(a.qkv.weight))
             if a.qkv.bias is not None:
                 ops.colsum(dqkv_part if dqkv_part is not None else dqkv, pk.g(a.qkv.bias))
             dln1 = new(M, D, T)
