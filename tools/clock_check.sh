@@ -28,6 +28,7 @@ print("method 1 (in-kernel s_memtime / s_memrealtime, median over workgroups) vs
 print("MFMA-busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x wall x clock), dispatches of >= 10 ms only")
 big = [(k, v) for k, v in dur.items() if "gemm_fast_kernel" in v[1] and k in cnt]
 big.sort(key=lambda kv: int(kv[0]))
+big = big[-7 * len(probes):]                       # the probe's own dispatches (7 per shape) follow the warm-up launches
 # per shape: 3 warm + 3 timed + 1 stamped dispatches, in order
 for i, p in enumerate(probes):
     grp = big[i * 7:(i + 1) * 7][3:6]
