@@ -2,7 +2,7 @@
 # usage (here, after tools/refresh_profiles.sh ran on the GPU box): tools/collect_profiles.sh [tag]
 # copies the judged summaries from gpurun_out/ (scratch) into profiles/ (tracked)
 set -e
-T=${1:-r02}
+T=${1:-r03}
 G=gpurun_out
 P=profiles
 cp $G/${T}_bench_n1*.json $P/
@@ -19,5 +19,6 @@ for c in cait_S24_224_bs256 swin_tiny_patch4_window7_224_bs256; do
   cp $G/${T}_$c.txt $P/${T}_rocprofv3_summary_$c.txt
   cp $G/${T}_${c}_kernel_stats.csv $P/${T}_rocprofv3_kernel_stats_$c.csv
 done
+cp $G/${T}_vitb_clock.txt $P/${T}_clock_two_methods.txt
 cp $G/${T}_gemm_traffic_by_shape.txt $G/${T}_gemm_traffic_by_shape.json $P/
 ls $P | grep "^${T}_"

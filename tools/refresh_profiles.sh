@@ -4,7 +4,7 @@
 # traffic / MFMA-busy of the headline run, per-shape GEMM traffic, one bench line per configuration.
 # tools/collect_profiles.sh <tag> copies the judged files into profiles/.
 set -e
-T=${1:-r02}
+T=${1:-r03}
 Q="--no-parity --no-alt"
 python bench.py > gpurun_out/${T}_bench_n1.json 2>gpurun_out/${T}_bench_n1.err
 tools/prof.sh ${T}_vitb --steps 5 --warmup 2 $Q
@@ -23,4 +23,5 @@ for a in dino_vitb16 swin_tiny_patch4_window7_224 cait_S24_224; do
 done
 rm -f gpurun_out/${T}_shapes.txt
 tools/pmc_gemm_shapes.sh ${T}
+tools/clock_check.sh ${T}_vitb 32
 python tools/bench_print.py gpurun_out/${T}_bench_n1*.json
