@@ -871,3 +871,87 @@ def test_gemm_pair_shares_one_split_k_launch(ops, lib):
     ops.gemm_pair(DY0, X0, W0b, dev(dy2, bt), X1, W2)
     assert torch.equal(W0b, S0)
     assert_close("fallback dW2", W2, (dy2.double().t() @ x1.double()).float(), 2e-5)
+
+
+@pytest.mark.parametrize("layout,epi,cdt", [("nt", "store", torch.bfloat16), ("nt", "gelu", torch.bfloat16), ("nt", "res", torch.bfloat16),
+                                            ("nt", "res", torch.float32), ("nn", "store", torch.bfloat16), ("nn", "dgelu", torch.bfloat16)])
+def test_gemm_counted_prefetch_wait_equals_strict_wait(ops, lib, layout, epi, cdt):
+    """the first wait of a prefetched tile counts E_MIN epilogue stores as younger operations (gemm_fast.hip,
+    the INVARIANT next to E_MIN).  With vitmi_debug_gemm_strict_wait(1) that wait is vmcnt(0): both forms must give the
+    same bits on every epilogue, on a launch where workgroups walk two tiles each (320 tiles on 256 CUs)."""
+    import ctypes
+    from vit_torch_amd import _lib as L
+    from vit_torch_amd._lib import EPI_BIAS_GELU, EPI_DGELU, EPI_RESIDUAL, GEMM_FAST
+    raw = ctypes.CDLL(str(L.LIB_PATH))
+    M, N, K = 256 * 40, 256 * 8, 768
+    akm, bkm = True, layout == "nt"
+    g = torch.Generator("cpu").manual_seed(93)
+    bt = torch.bfloat16
+    A = dev(bf16_round(torch.randn(M, K, generator=g)), bt)
+    B = dev(bf16_round(torch.randn((N, K) if bkm else (K, N), generator=g) * 0.05), bt)
+    bias = dev(torch.randn(N, generator=g))
+    kw = dict(a_kmajor=akm, b_kmajor=bkm)
+    if epi == "gelu":
+        kw.update(epilogue=EPI_BIAS_GELU, bias=bias, aux_deriv=True)
+    elif epi == "res":
+        kw.update(epilogue=EPI_RESIDUAL, bias=bias, R=dev(torch.randn(M, N, generator=g), cdt))
+    elif epi == "dgelu":
+        kw.update(epilogue=EPI_DGELU, aux=dev(bf16_round(torch.randn(M, N, generator=g)), bt), aux_deriv=True)
+    outs = []
+    try:
+        for strict in (0, 1, 0):
+            raw.vitmi_debug_gemm_strict_wait(strict)
+            C = torch.full((M, N), float("nan"), device="cuda").to(cdt)
+            extra = dict(C2=torch.full((M, N), float("nan"), device="cuda").to(cdt)) if epi == "gelu" else {}
+            ops.gemm(A, B, C, impl=GEMM_FAST, **kw, **extra)
+            outs.append([C.float().cpu()] + [t.float().cpu() for t in extra.values()])
+            assert torch.isfinite(outs[-1][0]).all()
+    finally:
+        raw.vitmi_debug_gemm_strict_wait(0)
+    for a, b, c in zip(*outs):
+        assert torch.equal(a, b) and torch.equal(a, c), "counted and strict waits of a prefetched tile disagree"
+
+
+@pytest.mark.parametrize("layout,epi,cdt", [("nt", "res", torch.bfloat16), ("nt", "res", torch.float32), ("nn", "store", torch.bfloat16),
+                                            ("nt", "store", torch.bfloat16)])
+def test_gemm_tail_fixup_by_the_last_arriving_slice(ops, lib, layout, epi, cdt):
+    """Split tail (vitmi_debug_gemm_tail(1)): the remainder tiles' k-slices store raw partial tiles and the slice that
+    arrives LAST applies the epilogue (gemm_fast.hip FIX) instead of a finisher kernel.  Same
+    summation order as the finisher: the two forms must agree bit for bit and with the reference, on a launch whose
+    remainder is spread over all XCDs, repeated so that the arrival order varies."""
+    import ctypes
+    from vit_torch_amd import _lib as L
+    from vit_torch_amd._lib import EPI_RESIDUAL, GEMM_FAST
+    raw = ctypes.CDLL(str(L.LIB_PATH))
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    tiles_m = cus // 3 + 21                   # 3 column tiles: (cus + 63) tiles = one full round + a remainder of 63 <= cus / 3
+    M, N, K = 256 * tiles_m, 768, 2304
+    akm, bkm = True, layout == "nt"
+    g = torch.Generator("cpu").manual_seed(97)
+    bt = torch.bfloat16
+    a = bf16_round(torch.randn(M, K, generator=g))
+    b = bf16_round(torch.randn(N, K, generator=g) * 0.05)
+    A, B = dev(a, bt), dev(b if bkm else b.t().contiguous(), bt)
+    bias = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    r = bf16_round(r) if cdt == bt else r
+    kw = dict(a_kmajor=akm, b_kmajor=bkm)
+    want = a @ b.t()
+    if epi == "res":
+        kw.update(epilogue=EPI_RESIDUAL, bias=dev(bias), R=dev(r, cdt))
+        want = r + want + bias
+    outs = []
+    try:
+        raw.vitmi_debug_gemm_tail(1)
+        for fix in (1, 0, 1, 1):
+            raw.vitmi_debug_gemm_tail_fixup(fix)
+            C = torch.full((M, N), float("nan"), device="cuda").to(cdt)
+            ops.gemm(A, B, C, impl=GEMM_FAST, **kw)
+            outs.append(C.float().cpu())
+            assert torch.isfinite(outs[-1]).all(), f"fixup={fix}: some tile never received its epilogue"
+    finally:
+        raw.vitmi_debug_gemm_tail(-1)
+        raw.vitmi_debug_gemm_tail_fixup(1)
+    assert_close("tail fix-up", outs[0], want, 1e-4 if cdt == torch.float32 else TOL[bt])
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o), "fix-up by the last slice and the finisher kernel must agree bit for bit"

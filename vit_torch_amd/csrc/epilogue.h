@@ -33,6 +33,9 @@ struct GemmArgs {
   int rfold;                      // gemm_fast: stream the fp32 residual through LDS during the main loop
   int band;                       // gemm_fast: column-band width of the tile order (0 = row-major)
   int launch_flags;               // VITMI_LAUNCH_*
+  unsigned* zero_cnt; int zero_n;   // gemm_fast full-rounds launch: counters of the tail launch that follows, zeroed by workgroup 0
+  unsigned* fix_cnt;              // gemm_fast tail slices: arrival counters (one per tail tile); the last slice to arrive applies the epilogue
+  int strict_wait;                // gemm_fast debug: a prefetched tile waits vmcnt(0) instead of the counted wait (vitmi_debug_gemm_strict_wait)
   // gemm_fast split-K, PAIRED launch (vitmi_gemm_pair): a second product with the same K / layouts shares the grid;
   // tiles [0, tiles1) belong to this problem, [tiles1, tiles1 + tiles2) to the second one (tiles1 == 0: no pair)
   const void* A2; const void* B2; int64_t lda2, ldb2, M2, N2; int tiles1, tiles_n2; float* ws2;

@@ -13,6 +13,10 @@ size_t gemm_fast_workspace(const GemmArgs& g);
 
 // diagnostic only (tools/gemm_phases.py): block 0 of the PIPE=1 kernel accumulates
 // s_memtime stamps of its R / M phases and barrier waits into this buffer
+// debug hook: prefetched tiles of the persistent walk wait for EVERYTHING (vmcnt(0)) before their first slab is read,
+// instead of the counted wait that relies on the epilogue issuing at least E_MIN stores; results must be bit-identical
+static int g_gemm_strict_wait = 0;
+extern "C" void vitmi_debug_gemm_strict_wait(int on) { g_gemm_strict_wait = on != 0; }
 static unsigned long long* g_gemm_dbg = nullptr;
 static int g_gemm_dbg_blocks = 64;
 extern "C" void vitmi_debug_gemm_stamps(unsigned long long* buf) { g_gemm_dbg = buf; g_gemm_dbg_blocks = 64; }
@@ -185,6 +189,8 @@ static int build_args(const vitmi_gemm_desc* d, GemmArgs* out) {
   g.band = 0;
   g.stag_cycles = 0; g.stag_phases = 1;
   g.launch_flags = d->launch_flags;
+  g.strict_wait = g_gemm_strict_wait;
+  g.zero_cnt = nullptr; g.zero_n = 0; g.fix_cnt = nullptr;
   g.A2 = g.B2 = nullptr; g.lda2 = g.ldb2 = g.M2 = g.N2 = 0; g.tiles1 = g.tiles_n2 = 0; g.ws2 = nullptr;
   g.dbg = g_gemm_dbg;
   g.dbg_blocks = g_gemm_dbg_blocks;

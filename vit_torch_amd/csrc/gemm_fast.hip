@@ -313,7 +313,50 @@ __device__ __forceinline__ void tile_mn(int t, int tiles_m, int tiles_n, int ban
 // vmcnt of the first wait of a prefetched tile: the epilogue's VMEM operations are YOUNGER than the
 // prefetch, so they are added to the count of younger DMAs; only the stores to C are counted
 // (a lower bound: fewer outstanding operations than allowed is always safe).
-template <bool A_KM, bool B_KM, int MODE, typename TC, bool SPLITK = false, int PIPE = 0>
+// One tile's epilogue from its k-slices' raw fp32 partial tiles in `ws` ([splits][M][N]): rows summed over the slices in the
+// fixed order 0, 1, ... (deterministic; the same order and arithmetic as tail_epilogue_kernel), then epi_row.  Run by the
+// whole workgroup (512 threads: a thread = W columns of a row, full lines).
+template <int MODE, typename TC>
+__device__ __forceinline__ void tile_fixup(const float* __restrict__ ws, int splits, const EpiArgs& e, int64_t M, int64_t N,
+                                           int64_t m0, int64_t n0, int tid) {
+  constexpr int W = sizeof(TC) == 2 ? 8 : 4;
+  constexpr int TPR = 256 / W;                       // threads per 256-column row
+  constexpr int RPP = NTHREADS / TPR;                // rows per pass
+  const int64_t n = n0 + (tid % TPR) * W;
+  float b[W], gm[W];
+#pragma unroll
+  for (int i = 0; i < W; ++i) { b[i] = 0.f; gm[i] = 1.f; }
+  if (e.bias) loadv<float, W>(e.bias + n, b);
+  if (MODE == VITMI_EPI_RESIDUAL && e.gamma) loadv<float, W>(e.gamma + n, gm);
+#pragma unroll 2
+  for (int r = tid / TPR; r < 256; r += RPP) {
+    const int64_t m = m0 + r;
+    float v[W];
+    loadv<float, W>(ws + m * N + n, v);
+    for (int s = 1; s < splits; ++s) {
+      float t[W];
+      loadv<float, W>(ws + ((int64_t)s * M + m) * N + n, t);
+#pragma unroll
+      for (int i = 0; i < W; ++i) v[i] += t[i];
+    }
+    float x[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) x[i] = 0.f;
+    if (epi_has_side<MODE, TC>(e)) epi_side<MODE, TC, W>(e, m, n, x);
+    epi_row<MODE, TC, W>(e, m, n, v, b, gm, x);
+  }
+}
+
+// FIX (split-K instantiations of the split tail only): the k-slices of a tail tile store their raw partial tiles and take a
+// ticket on the tile's arrival counter; the slice that arrives LAST applies the epilogue to the sum (tile_fixup) — the
+// row-wise finisher kernel of round 2 (12-15 us per launch, 36 launches per ViT-B/16 step) is gone.  Inter-workgroup
+// visibility as the guide's split-K recipe prescribes: every storing wave drains its stores (vmcnt(0)), the workgroup's
+// barrier, lane 0's agent-scope RELEASE fence + its own vmcnt(0) (the compiler may drop the fence's), then the relaxed
+// agent-scope ticket; the last arriver's lane 0 issues ONE agent-scope ACQUIRE + vmcnt(0), a barrier, and every wave reads
+// the slabs with plain loads.  Nothing spins: a wrong counter could only leave a tile without its epilogue (the tests'
+// NaN-filled outputs would show it), never hang.  The counters are zeroed by the full-rounds launch that precedes the
+// slices on the same stream (GemmArgs::zero_cnt).
+template <bool A_KM, bool B_KM, int MODE, typename TC, bool SPLITK = false, int PIPE = 0, bool FIX = false>
 __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int tiles_n, int nwg,
                                                              int ntiles, int ksps, float* ws, int tile0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // stages | strips
@@ -325,6 +368,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
   constexpr int LPR = 64 / W;                      // lanes per 64-column row
   constexpr int RPI = 64 / LPR;                    // rows per wave instruction
   constexpr int NJ = 16 / RPI;                     // row groups per strip
+  // INVARIANT (the first wait of a prefetched tile depends on it): every epilogue variant issues AT LEAST E_MIN = 8 strips x NJ
+  // row groups UNCONDITIONAL vector-memory stores to C per wave AFTER the next tile's prologue DMAs (epi_row / the raw split-K
+  // store below: one storev per (mi, j), never predicated or merged).  `vmcnt(younger + E_MIN)` then leaves at most the
+  // epilogue's own operations outstanding, i.e. the prologue slab it is about to read has landed.  An epilogue that issued
+  // FEWER stores would under-wait.  Second outputs (C2), side loads and column sums only ADD operations (safe direction).
+  // Guard: vitmi_debug_gemm_strict_wait(1) replaces the counted wait by vmcnt(0);
+  // tests/test_ops_gpu.py::test_gemm_counted_prefetch_wait_equals_strict_wait compares both bit for bit on every epilogue.
   constexpr int E_MIN = 8 * NJ;                    // stores to C every epilogue issues
 
   // XCD-aware, bijective tile map (guide §5: blocks b and b+8 share an XCD): XCD x owns the
@@ -367,6 +417,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
   // epilogue start and end of the first tile of the first blocks, wave 0
   const bool dbg_tl = g.dbg != nullptr && (int)blockIdx.x < g.dbg_blocks && wave == 0;
   const bool dbg = g.dbg != nullptr && blockIdx.x == 0;   // wave-uniform
+  if constexpr (PERSIST) {
+    if (g.zero_cnt && blockIdx.x == 0 && tid < g.zero_n) g.zero_cnt[tid] = 0u;     // the tail launch that follows counts from 0
+  }
   unsigned long long tl0 = 0;
   if (dbg_tl) {
     tl0 = stamp();
@@ -495,7 +548,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
     {   // slab 0 has landed: everything issued after it may still fly (later slabs, the residual
         // strip, and, behind a prefetch, the previous tile's epilogue)
       const int younger = 4 * (min(ns, AHEAD) - 1) + ((RFOLD_T && rfold) ? 4 : 0);
-      if (prefetched) {
+      if (prefetched && g.strict_wait) wait_vm_c<0>();
+      else if (prefetched) {
         if (younger >= 12) wait_vm_c<12 + E_MIN>();
         else if (younger >= 8) wait_vm_c<8 + E_MIN>();
         else if (younger >= 4) wait_vm_c<4 + E_MIN>();
@@ -592,7 +646,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
     // PIPE == 2: two 64-deep stages (full-line LDS-DMA), the same two wave groups one
     // barrier apart; stage t+1 is issued at R(2t) into the buffer stage t-1 has just
     // vacated and waited for (vmcnt(0)) at the end of phase 2t+1.
-    if (prefetched) { if (nt > 1) wait_vm_c<8 + E_MIN>(); else wait_vm_c<E_MIN>(); }
+    if (prefetched && g.strict_wait) wait_vm_c<0>();
+    else if (prefetched) { if (nt > 1) wait_vm_c<8 + E_MIN>(); else wait_vm_c<E_MIN>(); }
     else wait_vm(nt > 1 ? 8 : 0);
     raw_barrier();
     if (grp == 1) raw_barrier();
@@ -722,6 +777,29 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
 #pragma unroll
           for (int i = 0; i < W; ++i) cs[i] += v[i];
         }
+      }
+    }
+  }
+  if constexpr (SPLITK && FIX) {
+    if (g.fix_cnt) {           // kernel-uniform
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // this wave's partial rows have left
+      __syncthreads();
+      unsigned* flag = reinterpret_cast<unsigned*>(smem + 48 * 1024);     // the stages are dead; the strips end at 32 KiB
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *flag = __hip_atomic_fetch_add(g.fix_cnt + (wg0 % ntiles), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      const unsigned ticket = *flag;
+      const int nsplit = nwg / ntiles;
+      if (ticket == (unsigned)(nsplit - 1)) {                             // workgroup-uniform: this slice arrived last
+        if (tid == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        tile_fixup<MODE, TC>(ws, nsplit, g.e, pM, pN, m0, n0, tid);
       }
     }
   }
@@ -857,11 +935,16 @@ static bool tail_plan_shape(const GemmArgs& g, int nwg, int* rem, int* splits, i
   if ((*splits - 1) * *ksps >= nt) return false;      // every slice must be non-empty
   return true;
 }
+// workspace of a split tail: the slices' partial slabs + one arrival counter per tile (rounded up to 4 KiB)
+static size_t tail_ws_bytes(const GemmArgs& g) { return (size_t)TAIL_SPLITS * g.M * g.N * sizeof(float) + 4096; }
 static bool tail_plan(const GemmArgs& g, int nwg, int* rem, int* splits, int* ksps) {
   if (g_tail_override == 0 || g.e.colsum_part || g.e.accumulate) return false;
   if (!tail_plan_shape(g, nwg, rem, splits, ksps, g_tail_override == 1)) return false;
-  return g.ws != nullptr && g.ws_bytes >= (size_t)TAIL_SPLITS * g.M * g.N * sizeof(float);
+  return g.ws != nullptr && g.ws_bytes >= tail_ws_bytes(g) && *rem <= NTHREADS;
 }
+static int g_tail_fixup = 1;
+// diagnostic / test hook: 0 = the round-2 form (row-wise finisher kernel after the slices), 1 = the last slice applies the epilogue
+extern "C" void vitmi_debug_gemm_tail_fixup(int on) { g_tail_fixup = on != 0; }
 
 static int g_rfold_override = -1;
 // diagnostic / test hook: 0 = epilogue reads the residual (round-1 behaviour), 1 / -1 = fold it in
@@ -983,11 +1066,25 @@ int launch_p(const GemmArgs& g_in, hipStream_t stream) {
     if (tail_plan(g, nwg, &rem, &splits, &ksps)) {
       const int full = nwg - rem;
       auto kmain = gemm_fast_kernel<A_KM, B_KM, MODE, TC, false, PIPE>;
-      auto ktail = gemm_fast_kernel<A_KM, B_KM, VITMI_EPI_STORE, float, true, PIPE>;
       constexpr int LDSM = lds_bytes<MODE, TC, false, PIPE>();
       if (int rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(kmain), LDSM, "gemm_fast")) return rc;
-      if (int rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(ktail), 2 * STAGE_BYTES, "gemm_fast(tail)")) return rc;
       float* ws = reinterpret_cast<float*>(g.ws);
+      unsigned* cnt = reinterpret_cast<unsigned*>(ws + (size_t)TAIL_SPLITS * g.M * g.N);
+      if (g_tail_fixup) {
+        // the last slice of a tile to arrive applies the epilogue itself (FIX): two launches instead of three
+        auto ktail = gemm_fast_kernel<A_KM, B_KM, MODE, TC, true, PIPE, true>;
+        if (int rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(ktail), 2 * STAGE_BYTES, "gemm_fast(tail)")) return rc;
+        GemmArgs gm = g, gt = g;
+        gm.zero_cnt = cnt; gm.zero_n = rem;
+        gt.fix_cnt = cnt;
+        hipLaunchKernelGGL(kmain, dim3(persistent_grid(full, g.launch_flags)), dim3(NTHREADS), LDSM, stream, gm, tiles_n, full, full, 0, (float*)nullptr, 0);
+        int rc = vitmi_check_launch("gemm_fast_kernel(full rounds)");
+        if (rc) return rc;
+        hipLaunchKernelGGL(ktail, dim3(rem * splits), dim3(NTHREADS), 2 * STAGE_BYTES, stream, gt, tiles_n, rem * splits, rem, ksps, ws, full);
+        return vitmi_check_launch("gemm_fast_kernel(tail slices + fix-up)");
+      }
+      auto ktail = gemm_fast_kernel<A_KM, B_KM, VITMI_EPI_STORE, float, true, PIPE>;
+      if (int rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(ktail), 2 * STAGE_BYTES, "gemm_fast(tail)")) return rc;
       hipLaunchKernelGGL(kmain, dim3(persistent_grid(full, g.launch_flags)), dim3(NTHREADS), LDSM, stream, g, tiles_n, full, full, 0, (float*)nullptr, 0);
       int rc = vitmi_check_launch("gemm_fast_kernel(full rounds)");
       if (rc) return rc;
@@ -1081,7 +1178,7 @@ size_t gemm_fast_workspace(const GemmArgs& g) {
   if (need == 0 && (g.e.mode == VITMI_EPI_STORE || g.e.mode == VITMI_EPI_RESIDUAL) && g_tail_override != 0 &&
       !g.e.colsum_part && !g.e.accumulate) {
     int rem, splits, ksps;
-    if (tail_plan_shape(g, tiles, &rem, &splits, &ksps, g_tail_override == 1)) need = (size_t)TAIL_SPLITS * g.M * g.N * sizeof(float);
+    if (tail_plan_shape(g, tiles, &rem, &splits, &ksps, g_tail_override == 1)) need = tail_ws_bytes(g);
   }
   return need;
 }
