@@ -453,7 +453,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
   }
   char* rstrip = smem + RF_BASE + wave * 2 * RF_STRIP;   // PIPE 3: this wave's two residual strip buffers
   // epilogue strip: above the stages (the stages may already be receiving the next tile)
-  float* tr = reinterpret_cast<float*>(PIPE == 3 ? rstrip + RF_STRIP : smem + (SPLITK ? 0 : 2 * STAGE_BYTES) + wave * 4096);
+  // (split-K launches own only the two stages' 128 KiB and have no prefetch in flight after the loop: their strips alias the
+  // dead stages whatever the loop.  Round 2 placed the PIPE 3 split-K strips above 128 KiB — outside the allocation, where LDS
+  // writes are dropped: the k-sliced tail of the fp32-stream fc2 forward lost the rows of waves 4-7.  Found by
+  // test_gemm_tail_fixup_by_the_last_arriving_slice[nt-res-fp32] in round 3.)
+  float* tr = reinterpret_cast<float*>(SPLITK ? smem + wave * 4096
+                                              : (PIPE == 3 ? rstrip + RF_STRIP : smem + 2 * STAGE_BYTES + wave * 4096));
 
   // plans of a tile + the DMAs that precede its main loop
   auto start_tile = [&](int64_t m0, int64_t n0) {
@@ -942,8 +947,14 @@ static bool tail_plan(const GemmArgs& g, int nwg, int* rem, int* splits, int* ks
   if (!tail_plan_shape(g, nwg, rem, splits, ksps, g_tail_override == 1)) return false;
   return g.ws != nullptr && g.ws_bytes >= tail_ws_bytes(g) && *rem <= NTHREADS;
 }
-static int g_tail_fixup = 1;
-// diagnostic / test hook: 0 = the round-2 form (row-wise finisher kernel after the slices), 1 = the last slice applies the epilogue
+// 0 (default) = row-wise finisher kernel after the slices (all 256 CUs sum the 79 tiles' slabs: 60 MB in 12-15 us);
+// 1 = the last slice of a tile to arrive applies the epilogue itself (FIX).  The in-kernel form was asked for by VERDICT r02
+// (item 1a), is built and tested (bit-identical results), and measured SLOWER inside the ViT-B/16 step, one box, interleaved:
+// 34.85 / 34.89 ms against 34.02 / 34.14 with the finisher.  Why: a tail tile's three slabs are 768 KB, which ONE workgroup
+// then reads back at the 40-65 GB/s a single CU gets for freshly written lines (12-19 us, on 79 of the 256 CUs), behind an
+// agent-scope release that writes back 256 KB of dirty lines per slice — the guide's own sizing rule (in-launch combine
+// pays for a few tens of KB per tile, not hundreds).  The separate finisher is 1 264 blocks over the whole chip.
+static int g_tail_fixup = 0;
 extern "C" void vitmi_debug_gemm_tail_fixup(int on) { g_tail_fixup = on != 0; }
 
 static int g_rfold_override = -1;
