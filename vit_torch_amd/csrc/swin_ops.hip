@@ -612,32 +612,33 @@ __global__ void relpos_gather_kernel(const float* __restrict__ table, const int6
   const int h = t / NN, ij = t % NN;
   bias[t] = table[index[ij] * H + h];
 }
-// dtable[t][h] = sum_{ij: index[ij]==t} dbias[h][ij]: one workgroup per table row t.  The threads scan the
-// index ONCE per chunk of 8 heads (a position matches t for at most N of the N*N entries, so the dbias loads
-// are rare) and keep one partial sum per head; wave_sum + a fixed-order fold over the 4 waves (deterministic).
-// (Round 2 scanned the whole index once per head and wave: 33 us per call, 0.4 ms of the Swin-T step.)
+// dtable[t][h] = sum_{ij: index[ij]==t} dbias[h][ij]: one workgroup per table row t.  Phase 1: the threads scan
+// the index ONCE and compact the matching positions (at most N of the N*N) into LDS in a FIXED slot order
+// ((iteration, wave) slots, ballot-ranked inside a slot); phase 2: one thread per head sums its <= N values in that
+// order (deterministic, no atomics).  (Round 2 scanned the whole index once per head and wave: 33 us per call.)
 __global__ __launch_bounds__(256) void relpos_scatter_kernel(const float* __restrict__ dbias,
                                                             const int64_t* __restrict__ index,
                                                             float* __restrict__ dtable, int T, int H, int NN) {
-  __shared__ float red[4][8];
+  __shared__ int list[64 * 64];        // NN <= 4096: 16 iterations x 4 waves slots of up to 64 hits
+  __shared__ int cnt[64];
   const int t = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int h0 = 0; h0 < H; h0 += 8) {
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int ij = threadIdx.x; ij < NN; ij += 256)
-      if (index[ij] == t) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-          if (h0 + k < H) acc[k] += dbias[(int64_t)(h0 + k) * NN + ij];
-      }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float v = wave_sum(acc[k]);
-      if (lane == 0) red[w][k] = v;
+  const int iters = (NN + 255) / 256;
+  for (int it = 0; it < iters; ++it) {
+    const int ij = it * 256 + threadIdx.x;
+    const bool hit = ij < NN && index[ij] == t;
+    const unsigned long long m = __ballot(hit);
+    const int slot = it * 4 + w;
+    if (hit) list[slot * 64 + __popcll(m & ((1ull << lane) - 1ull))] = ij;
+    if (lane == 0) cnt[slot] = __popcll(m);
+  }
+  __syncthreads();
+  for (int h = threadIdx.x; h < H; h += 256) {
+    float s = 0.f;
+    for (int slot = 0; slot < iters * 4; ++slot) {
+      const int c = cnt[slot];
+      for (int e = 0; e < c; ++e) s += dbias[(int64_t)h * NN + list[slot * 64 + e]];
     }
-    __syncthreads();
-    if (threadIdx.x < 8 && h0 + (int)threadIdx.x < H)
-      dtable[(int64_t)t * H + h0 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    __syncthreads();
+    dtable[(int64_t)t * H + h] = s;
   }
 }
 
@@ -783,6 +784,7 @@ extern "C" int vitmi_win_attn_bwd(const void* qkv, const void* dout, const float
 extern "C" int vitmi_relpos_bias(const float* table, const int64_t* index, float* bias, const float* dbias,
                                  float* dtable, int64_t T, int64_t H, int64_t N, void* stream_) {
   VITMI_REQUIRE(index && T > 0 && H > 0 && N > 0, VITMI_E_BADARG, "relpos_bias: bad argument");
+  VITMI_REQUIRE(N <= 64, VITMI_E_SHAPE, "relpos_bias: windows of at most 64 tokens (N = %lld)", (long long)N);
   VITMI_REQUIRE((table && bias) || (dbias && dtable), VITMI_E_BADARG, "relpos_bias: need (table,bias) and/or (dbias,dtable)");
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   const int NN = (int)(N * N);
