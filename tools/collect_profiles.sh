@@ -20,5 +20,8 @@ for c in cait_S24_224_bs256 swin_tiny_patch4_window7_224_bs256; do
   cp $G/${T}_${c}_kernel_stats.csv $P/${T}_rocprofv3_kernel_stats_$c.csv
 done
 cp $G/${T}_vitb_clock.txt $P/${T}_clock_two_methods.txt
+cp $G/${T}_hbm_rate_*.txt $P/
+cp $G/${T}_ab_round_switches.txt $P/
+for a in cait_S24_224 swin_tiny_patch4_window7_224; do cp $G/${T}_${a}_pmc_traffic.txt $P/${T}_pmc_traffic_$a.txt; done
 cp $G/${T}_gemm_traffic_by_shape.txt $G/${T}_gemm_traffic_by_shape.json $P/
 ls $P | grep "^${T}_"

@@ -12,7 +12,7 @@ python3 tools/pmc_traffic.py gpurun_out/${tag}_fetch gpurun_out/${tag}_write gpu
 rm -rf gpurun_out/${tag}_fetch gpurun_out/${tag}_write
 # third pass: matrix-pipe busy cycles against the chip's active cycles (MFMA-busy fraction)
 cd /tmp
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/${tag}_mfma -- python3 $R/bench.py --no-cpu-baseline "$@" > $R/gpurun_out/${tag}_mfma.log 2>&1 || true
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/${tag}_mfma -- python3 $R/bench.py --no-cpu-baseline "$@" > $R/gpurun_out/${tag}_mfma.log 2>&1 || true
 cd $R
-python3 tools/pmc_mfma.py gpurun_out/${tag}_mfma gpurun_out/${tag}_pmc_mfma.json > gpurun_out/${tag}_pmc_mfma.txt || true
+python3 tools/pmc_mfma.py gpurun_out/${tag}_mfma gpurun_out/${tag}_pmc_mfma.json ${PMC_CLOCK_MHZ:-} > gpurun_out/${tag}_pmc_mfma.txt || true
 rm -rf gpurun_out/${tag}_mfma
