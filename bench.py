@@ -60,6 +60,11 @@ def parse():
                          "on = always, with the gradient all-reduce captured inside for N > 1)")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the run with the other residual-stream dtype")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of a multi-rank run (nccl = RCCL, the measured path; gloo: control-flow "
+                         "rehearsal of the multi-rank line on fewer GPUs than ranks, see --single-device)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="every rank uses cuda:0 (tests only: with --dist-backend gloo the N-rank code path runs on one GPU)")
     ap.add_argument("--force-ddp", action="store_true",
                     help="run the RCCL gradient exchange even in a world of one rank (launcher / ordering test)")
     ap.add_argument("--cpu-batch", type=int, default=16)
@@ -292,6 +297,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but the launcher started {world} ranks (WORLD_SIZE={world})")
+    if a.single_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
@@ -299,7 +306,10 @@ def main():
     if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from vit_torch_amd import CrossEntropyLoss, FusedSGD
     from vit_torch_amd.ddp import GradReducer
@@ -399,11 +409,15 @@ def main():
     loss_value = float(loss.item())
 
     # ---- instrumented step: per-launch GEMM durations (HIP events, launch stream) ----
+    # EVERY rank runs the instrumented step (it contains the gradient exchange: rank 0 alone would wait for its peers
+    # forever — the multi-rank line of rounds 1-2 had exactly that defect and was never run on more than one rank);
+    # only rank 0 brackets the launches with events and reports
     roof = None
-    if rank == 0:
-        eng.profile = []
+    if ddp or rank == 0:
+        eng.profile = [] if rank == 0 else None
         eager_step()
         torch.cuda.synchronize()
+    if rank == 0:
         rows = {}
         for name, shape, flops, e0, e1 in eng.profile:
             r = rows.setdefault((name, shape), [0, 0.0, 0.0])
@@ -537,6 +551,7 @@ def main():
                 dist.destroy_process_group()
             raise SystemExit(3)
     if ddp:
+        dist.barrier()                 # the other ranks wait for rank 0's reporting legs before the group goes away
         dist.destroy_process_group()
 
 

@@ -203,3 +203,27 @@ def test_bench_launches_itself_and_runs_the_rccl_path_end_to_end():
     assert r2.returncode == 0, r2.stderr[-2000:]
     d2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
     assert d2["config"]["hip_graph"] is True and d2["value"] > d["value"], (d2["value"], d["value"])
+
+
+def test_bench_two_rank_line_on_one_gpu_over_gloo():
+    """The multi-rank control flow of bench.py END TO END with two real ranks: launcher -> torch.distributed.run -> warm-up,
+    timed steps with the bucketed exchange, max-over-ranks time, the instrumented step (every rank must run it: it contains
+    collectives — rounds 1-2 ran it on rank 0 only, which would have hung any N > 1 run), one JSON line from rank 0.
+    One GPU here, so the two ranks share cuda:0 and exchange over gloo (`--dist-backend gloo --single-device`); on the
+    8-GPU node the same code runs one rank per GPU over RCCL."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--dist-backend", "gloo", "--single-device", "--steps", "2", "--warmup", "1",
+           "--arch", "dino_vits16", "--img", "32", "--batch", "64", "--no-cpu-baseline", "--no-parity"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0)"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 128
+    assert d["value"] > 0 and d["roofline"] is not None and d["config"]["hip_graph"] is False
