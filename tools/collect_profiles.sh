@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (here, after tools/refresh_profiles.sh ran on the GPU box): tools/collect_profiles.sh [tag]
 # copies the judged summaries from gpurun_out/ (scratch) into profiles/ (tracked)
-set -e
+set +e
 T=${1:-r03}
 G=gpurun_out
 P=profiles
