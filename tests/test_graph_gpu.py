@@ -75,3 +75,21 @@ def test_network_harness_with_hip_graph_matches_eager_harness(lib):
         assert hist[True][e]["train"]["loss"] == pytest.approx(hist[False][e]["train"]["loss"], rel=1e-5, abs=1e-6)
         assert (hist[True][e]["train"]["correct"] == hist[False][e]["train"]["correct"]).all()
     torch.testing.assert_close(hist[True][2], hist[False][2], rtol=1e-5, atol=1e-6)
+
+
+def test_graph_static_inputs_written_in_place(lib):
+    """A loader may write its batch straight into the graph's static inputs (step.x / step.y) and pass them back:
+    no copy is made, and the replay sees the new batch exactly as the copying call does."""
+    from vit_torch_amd.graph import GraphedStep
+    data = _batches(4)
+    ma, crita, opta = _make()
+    mb, critb, optb = _make()                      # same seed: same initial weights
+    a = GraphedStep(ma, crita, opta, *data[0], warmup=1)
+    b = GraphedStep(mb, critb, optb, *data[0], warmup=1)
+    for x, y in data[1:]:
+        la = a(x, y).item()                        # copied into the static inputs by the call
+        b.x.copy_(x)
+        b.y.copy_(y)
+        lb = b(b.x, b.y).item()                    # written in place by the "loader"
+        assert la == lb
+    assert torch.equal(ma.engine().pack.flat, mb.engine().pack.flat)

@@ -271,6 +271,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(const bf16* __re
 //                                         from [row][d] images the same way
 //   dQ^T += K^T dS^T                      B operand = the dS accumulators themselves
 constexpr int TP = 160;                // pitch of the [64 q][64 key] bf16 tile
+static int g_win_bwd_prefetch = 1;     // diagnostic hook (vitmi_debug_win_bwd_prefetch): L2 prefetch of a wave's next window
 constexpr int WIN_BWD_LDS = 3 * 64 * WP + 64 * TP;     // Q, K, dO images + tile, per wave
 
 __device__ __forceinline__ void win_store_T(bf16* dst, const f32x4& acc, float mul, int g) {
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const bf16* __re
                                                                bf16* __restrict__ dqkv, float* __restrict__ dbias_part,
                                                                float* __restrict__ qkvb_part,
                                                                WinGeom geo, int H, int N, float scale, int64_t Bw,
-                                                               int nwaves) {
+                                                               int nwaves, int pf_dump) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -370,6 +371,28 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const bf16* __re
           dpt[kb][qb][r] = ds;                     // now dS^T
           dsum[kb][qb][r] += ds;
         }
+    }
+    // ---- L2 prefetch of this wave's NEXT window (round 3).  A wave walks its windows serially — load, wait, compute,
+    // store — at one wave per SIMD, so every HBM round trip of a window is exposed (two per window: the staging batch and
+    // the V fragments).  All loads of the current window have been consumed at this point and ~60 % of its arithmetic is
+    // still ahead: each 64-B row piece (Q, K, V, dO of every token) of the next window is touched by a 4-byte LDS-DMA
+    // (4 N lanes = 4 instructions, no VGPR destination, the dwords land in a 256-B dump behind the workgroup's LDS), so
+    // the next iteration's loads find their lines in this XCD's L2.  Inline asm: hipcc need not know about them — they
+    // are older than every load whose data is used and vmcnt retires in order.
+    if (pf_dump >= 0 && bw + wstep < Bw) {
+      const int64_t bwn = bw + wstep;
+      int lane_p = lane;
+      asm volatile("" : "+v"(lane_p));
+#pragma unroll 1
+      for (int p = lane_p; p < 4 * N; p += 64) {
+        const int m = p / N, r = p - m * N;
+        const int64_t tok = win_token(geo, bwn, r);
+        const char* src = m < 3 ? reinterpret_cast<const char*>(qkv + tok * ts + (m * H + h) * 32)
+                                : reinterpret_cast<const char*>(dout + tok * os + h * 32);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(pf_dump) : "memory");
+      }
     }
     // ---- P -> tile [q][key]; dV^T[d][key] = sum_q dO^T[d][q] P[q][key]
 #pragma unroll
@@ -755,10 +778,11 @@ extern "C" int vitmi_win_attn_bwd(const void* qkv, const void* dout, const float
     if (per_head < 1) per_head = 1;
     const int nwaves = (int)(per_head * H);
     auto kern = win_attn_bwd_mfma_kernel;
-    if ((rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(kern), 4 * WIN_BWD_LDS, "win_attn_bwd"))) return rc;
+    if ((rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(kern), 4 * WIN_BWD_LDS + 256, "win_attn_bwd"))) return rc;
     float* qb_part = dqkv_bias ? part + per_head * H * N * N : nullptr;     // [per_head][3*H*32]
-    hipLaunchKernelGGL(kern, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 4 * WIN_BWD_LDS, stream, (const bf16*)qkv,
-                       (const bf16*)dout, lse, bias, mask, (bf16*)dqkv, part, qb_part, g, (int)H, (int)N, scale, Bw, nwaves);
+    const int pf_dump = g_win_bwd_prefetch ? 4 * WIN_BWD_LDS : -1;           // LDS offset of the prefetch dump, -1 = off
+    hipLaunchKernelGGL(kern, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 4 * WIN_BWD_LDS + 256, stream, (const bf16*)qkv,
+                       (const bf16*)dout, lse, bias, mask, (bf16*)dqkv, part, qb_part, g, (int)H, (int)N, scale, Bw, nwaves, pf_dump);
     if ((rc = vitmi_check_launch("win_attn_bwd_mfma_kernel"))) return rc;
     if ((rc = vitmi_reduce_rows(part, (int)per_head, H * N * N, H * N * N, dbias, stream))) return rc;
     if (dqkv_bias) return vitmi_reduce_rows(qb_part, (int)per_head, 3 * H * 32, 3 * H * 32, dqkv_bias, stream);
@@ -780,6 +804,8 @@ extern "C" int vitmi_win_attn_bwd(const void* qkv, const void* dout, const float
   // deterministic reduction of the per-window d(score) tiles: rows = windows, cols = H*N*N
   return vitmi_reduce_rows(part, (int)Bw, H * N * N, H * N * N, dbias, stream);
 }
+
+extern "C" void vitmi_debug_win_bwd_prefetch(int on) { g_win_bwd_prefetch = on; }
 
 extern "C" int vitmi_relpos_bias(const float* table, const int64_t* index, float* bias, const float* dbias,
                                  float* dtable, int64_t T, int64_t H, int64_t N, void* stream_) {
