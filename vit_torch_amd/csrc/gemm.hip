@@ -156,6 +156,8 @@ static int g_nt_min_mb = 64;         // diagnostic hook: outputs / side inputs o
 extern "C" void vitmi_debug_gemm_nt_min_mb(int mb) { g_nt_min_mb = mb > 0 ? mb : 64; }
 static int g_side_nt = -1;           // diagnostic hook: -1 = automatic (wide side inputs), 0 / 1 forced
 extern "C" void vitmi_debug_gemm_side_nt(int v) { g_side_nt = v; }
+static int g_side_depth = 3;         // diagnostic hook: strips of the epilogue's side input in flight (bf16 outputs): 1 or 3
+extern "C" void vitmi_debug_gemm_side_depth(int d) { g_side_depth = d >= 3 ? 3 : 1; }
 static int side_policy(const vitmi_gemm_desc* d) {
   if (g_side_nt >= 0) return g_side_nt;
   return d->M * d->N * 2 >= ((int64_t)g_nt_min_mb << 20) ? 1 : 0;
@@ -188,6 +190,7 @@ static int build_args(const vitmi_gemm_desc* d, GemmArgs* out) {
   g.rfold = 0;
   g.band = 0;
   g.stag_cycles = 0; g.stag_phases = 1;
+  g.side_depth = g_side_depth;
   g.launch_flags = d->launch_flags;
   g.strict_wait = g_gemm_strict_wait;
   g.zero_cnt = nullptr; g.zero_n = 0; g.fix_cnt = nullptr;

@@ -22,6 +22,7 @@
 // Block -> tile map is XCD-aware (8 XCDs, private L2s): each XCD walks a
 // contiguous run of tiles, n fastest, so the A panel of a row of tiles and the
 // whole weight matrix stay in that XCD's L2.
+#include <type_traits>
 #include "gemm_tile.h"
 
 namespace {
@@ -32,7 +33,7 @@ constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + B
 constexpr int NTHREADS = 512;
 
 // ---- staging: each wave issues 4 LDS-DMA instructions (1 KiB each) per tile
-template <bool KM>
+template <bool KM, bool HID = false>
 __device__ __forceinline__ void stage_tile(char* tile, const bf16* __restrict__ X, int64_t ld,
                                            int64_t r0, int64_t k0, int wave, int lane) {
   if constexpr (KM) {
@@ -44,7 +45,7 @@ __device__ __forceinline__ void stage_tile(char* tile, const bf16* __restrict__ 
       const int st = wave * 4 + i;          // subtile: 16 rows x 32 k
       const int sr = st >> 1, kh = st & 1;
       const bf16* src = X + (r0 + sr * 16 + row) * ld + k0 + kh * 32 + ch * 8;
-      glds16(src, tile + st * 1024);
+      glds16x<HID>(src, tile + st * 1024);
     }
   } else {
 #pragma unroll
@@ -55,7 +56,7 @@ __device__ __forceinline__ void stage_tile(char* tile, const bf16* __restrict__ 
       const int key = (row & 3) | (((row >> 3) & 1) << 2);
       const int c32 = (pc16 >> 1) ^ key;
       const bf16* src = X + (k0 + row) * ld + r0 + c32 * 16 + (pc16 & 1) * 8;
-      glds16(src, tile + j * 1024);
+      glds16x<HID>(src, tile + j * 1024);
     }
   }
 }
@@ -119,10 +120,11 @@ template <bool KM> struct SlabPlan {
       step = 64 * ld;
     }
   }
+  template <bool HID = false>
   __device__ __forceinline__ void issue(char* slab, int j, int wave) const {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      glds16(base[i] + (int64_t)j * step + off[i], slab + (wave * 2 + i) * 1024);
+      glds16x<HID>(base[i] + (int64_t)j * step + off[i], slab + (wave * 2 + i) * 1024);
   }
 };
 
@@ -172,10 +174,11 @@ template <bool KM> struct StagePlan {
     }
     step = KM ? 128 : 128 * ld;
   }
+  template <bool HID = false>
   __device__ __forceinline__ void issue(char* tile, int t, int wave) const {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      glds16(base[i] + (int64_t)t * step + off[i], tile + (wave * 4 + i) * 1024);
+      glds16x<HID>(base[i] + (int64_t)t * step + off[i], tile + (wave * 4 + i) * 1024);
   }
 };
 // per-lane LDS byte offset (k-half 0) of the fragment of block rb in a 64-deep stage
@@ -240,9 +243,10 @@ struct ResFold {
     }
     lr = lane & 15; lg = lane >> 4;
   }
+  template <bool HID = false>
   __device__ __forceinline__ void issue(char* strip, int s) const {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(base + (int64_t)s * strip_step + off[i], strip + i * 1024);
+    for (int i = 0; i < 4; ++i) glds16x<HID>(base + (int64_t)s * strip_step + off[i], strip + i * 1024);
   }
   // the wave's accumulator-shaped view of the strip: f32x4 of (row lr, columns 16 ni + 4 lg ..)
   __device__ __forceinline__ void read(const char* strip, u32x4 (&r)[4]) const {
@@ -356,7 +360,9 @@ __device__ __forceinline__ void tile_fixup(const float* __restrict__ ws, int spl
 // the slabs with plain loads.  Nothing spins: a wrong counter could only leave a tile without its epilogue (the tests'
 // NaN-filled outputs would show it), never hang.  The counters are zeroed by the full-rounds launch that precedes the
 // slices on the same stream (GemmArgs::zero_cnt).
-template <bool A_KM, bool B_KM, int MODE, typename TC, bool SPLITK = false, int PIPE = 0, bool FIX = false>
+// DEEP: 0 = side inputs one strip ahead (every epilogue); 1 = three strips ahead, packed (bf16 RESIDUAL / DGELU);
+// 2 = the same for the PLAIN residual epilogue (no second output, no row scale, plain stores) as straight-line code
+template <bool A_KM, bool B_KM, int MODE, typename TC, bool SPLITK = false, int PIPE = 0, bool FIX = false, int DEEP = 0>
 __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int tiles_n, int nwg,
                                                              int ntiles, int ksps, float* ws, int tile0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // stages | strips
@@ -461,7 +467,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
                                               : (PIPE == 3 ? rstrip + RF_STRIP : smem + 2 * STAGE_BYTES + wave * 4096));
 
   // plans of a tile + the DMAs that precede its main loop
-  auto start_tile = [&](int64_t m0, int64_t n0) {
+  // hid (a std::bool_constant): the DMAs go out from inline asm, unseen by hipcc — the prologue issued in front of an
+  // epilogue (glds16_hidden)
+  auto start_tile = [&](int64_t m0, int64_t n0, auto hid) {
+    constexpr bool HID = decltype(hid)::value;
     if constexpr (RINGP) {
       sa.init(A, lda, m0, kb0, wave, lane);
       sb.init(B, ldb, n0, kb0, wave, lane);
@@ -470,22 +479,22 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
       for (int a = 0; a < AHEAD; ++a)
         if (a < ns) {
           char* st = smem + a * RING_STAGE;
-          sa.issue(st, a, wave);
-          sb.issue(st + SLAB_BYTES, a, wave);
+          sa.template issue<HID>(st, a, wave);
+          sb.template issue<HID>(st + SLAB_BYTES, a, wave);
         }
-      if constexpr (RFOLD_T) { if (rfold) rf.issue(rstrip, 0); }     // strip 0 rides behind the prologue slabs
+      if constexpr (RFOLD_T) { if (rfold) rf.template issue<HID>(rstrip, 0); }     // strip 0 rides behind the prologue slabs
     } else if constexpr (PIPE == 2) {
       ta.init(A, lda, m0, kb0, wave, lane);
       tb.init(B, ldb, n0, kb0, wave, lane);
-      ta.issue(smem, 0, wave);
-      tb.issue(smem + TILE_BYTES, 0, wave);
+      ta.template issue<HID>(smem, 0, wave);
+      tb.template issue<HID>(smem + TILE_BYTES, 0, wave);
       if (nt > 1) {
-        ta.issue(smem + STAGE_BYTES, 1, wave);
-        tb.issue(smem + STAGE_BYTES + TILE_BYTES, 1, wave);
+        ta.template issue<HID>(smem + STAGE_BYTES, 1, wave);
+        tb.template issue<HID>(smem + STAGE_BYTES + TILE_BYTES, 1, wave);
       }
     } else {                       // PIPE 0: stage 0 (the loop issues stage t + 1 itself)
-      stage_tile<A_KM>(smem, A, lda, m0, kb0, wave, lane);
-      stage_tile<B_KM>(smem + TILE_BYTES, B, ldb, n0, kb0, wave, lane);
+      stage_tile<A_KM, HID>(smem, A, lda, m0, kb0, wave, lane);
+      stage_tile<B_KM, HID>(smem + TILE_BYTES, B, ldb, n0, kb0, wave, lane);
     }
   };
 
@@ -494,7 +503,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
   int mt_, nt_;
   tile_mn(tile, tiles_m, tiles_n, g.band, &mt_, &nt_);
   int64_t m0 = (int64_t)mt_ * BM, n0 = (int64_t)nt_ * BN;
-  start_tile(m0, n0);
+  start_tile(m0, n0, std::false_type{});
   bool prefetched = false;                         // the tile's prologue DMAs were issued before an epilogue
   // Start stagger: a launch of q full rounds plus a remainder leaves most workgroups one tile short of
   // the longest list, i.e. idle for a tile time at the end.  Those workgroups instead start late by a
@@ -728,16 +737,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
   if constexpr (PERSIST) {
     const int nidx = idx + gx;
     has_next = nidx < x_len;
+    // bias / LayerScale first and waited for with a wait the compiler SEES: while an LDS-DMA is
+    // in flight hipcc answers the first use of any ordinary load with vmcnt(0), which would
+    // put the whole prefetch in front of the epilogue.  On BOTH paths (round 3): the main loop's DMAs are retired by
+    // asm waits hipcc does not see, so without this it still believes them pending when the last tile's epilogue
+    // (no prefetch) meets the prefetching path at the join, and answers the first side-input use with vmcnt(0) again.
+    __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): nothing but these two small loads is outstanding
     if (has_next) {
-      // bias / LayerScale first and waited for with a wait the compiler SEES: while an LDS-DMA is
-      // in flight hipcc answers the first use of any ordinary load with vmcnt(0), which would
-      // put the whole prefetch in front of the epilogue
-      __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): nothing but these two small loads is outstanding
       const int tn = x_start + nidx;
       tile_mn(tn, tiles_m, tiles_n, g.band, &mt_, &nt_);
       m0n = (int64_t)mt_ * BM;
       n0n = (int64_t)nt_ * BN;
-      start_tile(m0n, n0n);
+      // the DEEP epilogues wait for their side loads with hipcc's own counted vmcnt: their prologue goes out unseen
+      // (a run-time choice between the two forms would leave the builtin's pending DMA in hipcc's state at the join)
+      start_tile(m0n, n0n, std::bool_constant<DEEP != 0>{});
     }
   }
   // (residual fold: R is already inside the accumulators; x = 0, gamma = 1 -> v = acc + b)
@@ -746,15 +759,90 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
   float cs[W];                                     // DGELU: column sums of this lane's rows
 #pragma unroll
   for (int i = 0; i < W; ++i) cs[i] = 0.f;
+  // DEEP (bf16 outputs with a per-element side input: the bf16 residual stream, the saved gelu'): THREE strips of the side
+  // input in flight, kept packed (4 registers per 16-B piece: 24 registers, fewer than the two unpacked strips of round 2).
+  // One strip ahead gives a load the ~1.9 k cycles a strip takes to process; under the epilogue burst of all CUs an HBM
+  // round trip is 3-5 k, so every strip waited (ISA: `vmcnt(2)` in front of each, ~2 k cycles each = the 15 k-cycle
+  // DGELU epilogue).  Three ahead cover it.
+  constexpr bool DEEP_T = DEEP != 0 && !SPLITK && W == 8 && (MODE == VITMI_EPI_RESIDUAL || MODE == VITMI_EPI_DGELU);
+  bool deep_done = false;
+  if constexpr (DEEP_T) {
+    if (side) {                                      // kernel-uniform
+      deep_done = true;
+      const bf16* sbase = MODE == VITMI_EPI_RESIDUAL ? reinterpret_cast<const bf16*>(g.e.R) : reinterpret_cast<const bf16*>(g.e.AUX);
+      const int64_t sld = MODE == VITMI_EPI_RESIDUAL ? g.e.ldr : g.e.ldaux;
+      bf16x8 sp[3][NJ];
+      auto side_load = [&](int strip, bf16x8 (&dst)[NJ]) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const bf16x8* p = reinterpret_cast<const bf16x8*>(sbase + row_off(m0 + wm * 128 + strip * 16 + j * RPI, rr, sld, ncol));
+          dst[j] = g.e.side_nt ? __builtin_nontemporal_load(p) : *p;
+        }
+      };
+      side_load(0, sp[0]);
+      asm volatile("" ::: "memory");                 // keep the issue order: the first strip's data must be the oldest
+      side_load(1, sp[1]);
+      asm volatile("" ::: "memory");
+      side_load(2, sp[2]);
+      asm volatile("" ::: "memory");
+      // PLAIN (DEEP == 2): the residual epilogue of every ViT / Swin block without DropPath (no second output, no row
+      // scale, plain stores) and the gelu'-multiply with `nt` stores, as straight-line code.  The general row function
+      // branches on those run-time options around loads and stores; at every join hipcc must assume the conditional
+      // store / load may not have been issued and its counted waits turn into drains (ISA: vmcnt(0) in front of every row
+      // of the residual strip; vmcnt(5) where nine operations could have stayed in flight in the gelu' one).
+      auto deep_loop = [&](auto plain_tag) {
+        constexpr bool PLAIN = decltype(plain_tag)::value;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+            *reinterpret_cast<f32x4*>(strip_at(tr, lr, ni * 16 + lg * 4)) = acc[ni][mi];
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const int row = j * RPI + rr;
+            float v[W], x[W];
+#pragma unroll
+            for (int qq = 0; qq < W / 4; ++qq) {
+              const f32x4 t4 = *reinterpret_cast<const f32x4*>(strip_at(tr, row, rc + 4 * qq));
+              v[4 * qq] = t4[0]; v[4 * qq + 1] = t4[1]; v[4 * qq + 2] = t4[2]; v[4 * qq + 3] = t4[3];
+            }
+#pragma unroll
+            for (int i = 0; i < W; ++i) x[i] = (float)sp[mi % 3][j][i];
+            if constexpr (PLAIN && MODE == VITMI_EPI_RESIDUAL) {
+#pragma unroll
+              for (int i = 0; i < W; ++i) v[i] = x[i] + gamma_r[i] * (v[i] + bias_r[i]);      // the arithmetic of epi_row with rs = 1
+              storev<TC, W>(reinterpret_cast<TC*>(g.e.C) + row_off(m0 + wm * 128 + mi * 16 + j * RPI, rr, g.e.ldc, ncol), v);
+            } else if constexpr (PLAIN && MODE == VITMI_EPI_DGELU) {
+#pragma unroll
+              for (int i = 0; i < W; ++i) v[i] *= x[i];                                       // AUX = gelu'(pre), `nt` store
+              bf16x8 o;
+#pragma unroll
+              for (int i = 0; i < W; ++i) o[i] = (bf16)v[i];
+              __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(reinterpret_cast<TC*>(g.e.C) + row_off(m0 + wm * 128 + mi * 16 + j * RPI, rr, g.e.ldc, ncol)));
+            } else {
+              epi_row<MODE, TC, W>(g.e, m0 + wm * 128 + mi * 16 + j * RPI, rr, ncol, v, bias_r, gamma_r, x);
+            }
+            if constexpr (MODE == VITMI_EPI_DGELU) {
+#pragma unroll
+              for (int i = 0; i < W; ++i) cs[i] += v[i];
+            }
+          }
+          if (mi + 3 < 8) side_load(mi + 3, sp[mi % 3]);
+        }
+      };
+      deep_loop(std::bool_constant<DEEP == 2>{});
+    }
+  }
   float sx[2][NJ][W];                              // side inputs: this strip and the next
 #pragma unroll
   for (int j = 0; j < NJ; ++j)
 #pragma unroll
     for (int i = 0; i < W; ++i) { sx[0][j][i] = 0.f; sx[1][j][i] = 0.f; }
-  if (side) {
+  if (side && !deep_done) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) epi_side<MODE, TC, W>(g.e, m0 + wm * 128 + j * RPI, rr, ncol, sx[0][j]);
   }
+  if (!deep_done) {
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi) {
     if (side && mi + 1 < 8) {
@@ -784,6 +872,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
         }
       }
     }
+  }
   }
   if constexpr (SPLITK && FIX) {
     if (g.fix_cnt) {           // kernel-uniform
@@ -1076,7 +1165,18 @@ int launch_p(const GemmArgs& g_in, hipStream_t stream) {
     int rem = 0, splits = 0, ksps = 0;
     if (tail_plan(g, nwg, &rem, &splits, &ksps)) {
       const int full = nwg - rem;
+      constexpr bool CAN_DEEP = sizeof(TC) == 2 && (MODE == VITMI_EPI_RESIDUAL || MODE == VITMI_EPI_DGELU);
       auto kmain = gemm_fast_kernel<A_KM, B_KM, MODE, TC, false, PIPE>;
+      if constexpr (CAN_DEEP) {
+        if (g.side_depth >= 3) {
+          kmain = gemm_fast_kernel<A_KM, B_KM, MODE, TC, false, PIPE, false, 1>;
+          if constexpr (MODE == VITMI_EPI_RESIDUAL) {
+            if (!g.e.C2 && !g.e.rowscale && g.e.c_policy == 0) kmain = gemm_fast_kernel<A_KM, B_KM, MODE, TC, false, PIPE, false, 2>;
+          } else {
+            if (g.e.aux_deriv && g.e.c_policy == 2) kmain = gemm_fast_kernel<A_KM, B_KM, MODE, TC, false, PIPE, false, 2>;
+          }
+        }
+      }
       constexpr int LDSM = lds_bytes<MODE, TC, false, PIPE>();
       if (int rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(kmain), LDSM, "gemm_fast")) return rc;
       float* ws = reinterpret_cast<float*>(g.ws);
@@ -1105,7 +1205,18 @@ int launch_p(const GemmArgs& g_in, hipStream_t stream) {
       return vitmi_check_launch("tail_epilogue_kernel");
     }
   }
+  constexpr bool CAN_DEEP2 = sizeof(TC) == 2 && (MODE == VITMI_EPI_RESIDUAL || MODE == VITMI_EPI_DGELU);
   auto kern = gemm_fast_kernel<A_KM, B_KM, MODE, TC, false, PIPE>;
+  if constexpr (CAN_DEEP2) {
+    if (g.side_depth >= 3) {
+      kern = gemm_fast_kernel<A_KM, B_KM, MODE, TC, false, PIPE, false, 1>;
+      if constexpr (MODE == VITMI_EPI_RESIDUAL) {
+        if (!g.e.C2 && !g.e.rowscale && g.e.c_policy == 0) kern = gemm_fast_kernel<A_KM, B_KM, MODE, TC, false, PIPE, false, 2>;
+      } else {
+        if (g.e.aux_deriv && g.e.c_policy == 2) kern = gemm_fast_kernel<A_KM, B_KM, MODE, TC, false, PIPE, false, 2>;
+      }
+    }
+  }
   constexpr int LDSK = lds_bytes<MODE, TC, false, PIPE>();
   if (int rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(kern), LDSK, "gemm_fast")) return rc;
   hipLaunchKernelGGL(kern, dim3(persistent_grid(nwg, g.launch_flags)), dim3(NTHREADS), LDSK, stream, g, tiles_n, nwg, nwg, 0, (float*)nullptr, 0);

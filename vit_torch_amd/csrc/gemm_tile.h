@@ -10,6 +10,23 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
+// The same LDS-DMA issued from inline asm: hipcc does not know of it.  Used for the NEXT tile's prologue stages, which are
+// issued in front of an epilogue: with the builtin form outstanding, hipcc answers the first use of the epilogue's ordinary
+// side-input loads (residual rows, saved gelu') with `s_waitcnt vmcnt(0)` — the whole prologue plus every side load issued
+// so far — instead of the counted wait it emits when it only sees loads and stores.  The prologue is waited for by the
+// counted `wait_vm_c` of the next tile's first slab, never by the compiler.  M0 (the DMA's LDS base) is compiler-reserved:
+// saved, written and restored inside the one statement (guide §5.7).
+__device__ __forceinline__ void glds16_hidden(const void* gsrc, char* lds_dst) {
+  unsigned keep;
+  const unsigned l = (unsigned)(uintptr_t)LDS_PTR(char, lds_dst);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(l) : "memory");
+}
+template <bool HID> __device__ __forceinline__ void glds16x(const void* gsrc, char* lds_dst) {
+  if constexpr (HID) glds16_hidden(gsrc, lds_dst);
+  else glds16(gsrc, lds_dst);
+}
+
 // A fragment in flight: for the k-major image one ds_read_b128 the compiler tracks; for
 // the k-row image two ds_read_b64_tr_b16 issued from INLINE ASM.  The builtin form makes
 // hipcc put `s_waitcnt vmcnt(0)` in front of every transposed read while an LDS-DMA is
@@ -178,15 +195,19 @@ __device__ __forceinline__ void storev_pol(T* p, const float (&v)[W], int policy
     bf16x8 o;
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = (bf16)v[i];
+    // `nt` through the builtin, NOT inline asm (round 3): an asm store is absent from hipcc's vmcnt bookkeeping, so the
+    // counted wait it emits for the NEXT strip's side-input loads (`vmcnt(2)` = "my two younger loads may fly") also
+    // drained the asm stores issued in between — every strip of the gelu'-multiply epilogue waited for the previous
+    // strip's stores to be acknowledged by memory.  (`sc1`, a diagnostic policy, has no builtin and stays asm.)
     if (policy == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(o) : "memory");
-    else asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(p), "v"(o) : "memory");
+    else __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(p));
   } else if constexpr (sizeof(T) == 4) {
 #pragma unroll
     for (int q = 0; q < W / 4; ++q) {
       const f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
       T* pq = p + 4 * q;
       if (policy == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(pq), "v"(o) : "memory");
-      else asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(pq), "v"(o) : "memory");
+      else __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(pq));
     }
   } else {
     storev<T, W>(p, v);
