@@ -912,6 +912,60 @@ def test_gemm_counted_prefetch_wait_equals_strict_wait(ops, lib, layout, epi, cd
         assert torch.equal(a, b) and torch.equal(a, c), "counted and strict waits of a prefetched tile disagree"
 
 
+@pytest.mark.parametrize("layout,epi", [("nt", "store"), ("nn", "store"), ("tn", "store"), ("nt", "gelu"), ("nt", "res"), ("nn", "dgelu")])
+@pytest.mark.parametrize("nt_mb", [1, 1 << 20])
+def test_gemm_straight_line_epilogues_equal_the_general_row_function(ops, lib, layout, epi, nt_mb):
+    """Round 3: the bf16 epilogues of the step exist as straight-line code (plain store / gelu + gelu' / gelu' multiply with
+    `nt` stores, the plain residual) with THREE strips of the side input in flight; vitmi_debug_gemm_side_depth(1) selects
+    the general row function with one strip ahead.  Same arithmetic: the outputs must agree bit for bit (gelu' to one bf16
+    ulp on a vanishing fraction: its formula is a chain of explicit fmas, but hipcc is free to keep an intermediate in a
+    different form), with the `nt` policy forced on (1 MB threshold) and off, on a launch where workgroups walk several tiles."""
+    import ctypes
+    from vit_torch_amd import _lib as L
+    from vit_torch_amd._lib import EPI_BIAS_GELU, EPI_DGELU, EPI_RESIDUAL, GEMM_FAST
+    raw = ctypes.CDLL(str(L.LIB_PATH))
+    M, N, K = 256 * 40, 256 * 8, 768
+    if layout == "tn":
+        M, N, K = 768, 2048, 256 * 40
+    akm, bkm = layout != "tn", layout == "nt"
+    g = torch.Generator("cpu").manual_seed(94)
+    bt = torch.bfloat16
+    A = dev(bf16_round(torch.randn((M, K) if akm else (K, M), generator=g)), bt)
+    B = dev(bf16_round(torch.randn((N, K) if bkm else (K, N), generator=g) * 0.05), bt)
+    bias = dev(torch.randn(N, generator=g))
+    kw = dict(a_kmajor=akm, b_kmajor=bkm)
+    if epi == "store" and layout == "nt":
+        kw.update(bias=bias)
+    elif epi == "gelu":
+        kw.update(epilogue=EPI_BIAS_GELU, bias=bias, aux_deriv=True)
+    elif epi == "res":
+        kw.update(epilogue=EPI_RESIDUAL, bias=bias, R=dev(bf16_round(torch.randn(M, N, generator=g)), bt))
+    elif epi == "dgelu":
+        kw.update(epilogue=EPI_DGELU, aux=dev(bf16_round(torch.randn(M, N, generator=g)), bt), aux_deriv=True,
+                  colsum_part=torch.full((M // 128, N), float("nan"), device="cuda"))
+    outs = []
+    try:
+        raw.vitmi_debug_gemm_nt_min_mb(nt_mb)
+        for depth in (1, 3, 1):
+            raw.vitmi_debug_gemm_side_depth(depth)
+            C = torch.full((M, N), float("nan"), device="cuda").to(bt)
+            extra = dict(C2=torch.full((M, N), float("nan"), device="cuda").to(bt)) if epi == "gelu" else {}
+            ops.gemm(A, B, C, impl=GEMM_FAST, **kw, **extra)
+            outs.append([C.float().cpu()] + [t.float().cpu() for t in extra.values()] +
+                        ([kw["colsum_part"].clone().cpu()] if epi == "dgelu" else []))
+            assert all(torch.isfinite(t).all() for t in outs[-1])
+    finally:
+        raw.vitmi_debug_gemm_side_depth(3)
+        raw.vitmi_debug_gemm_nt_min_mb(64)
+    for i, (a, b, c) in enumerate(zip(*outs)):
+        assert torch.equal(a, c)
+        if epi == "gelu" and i == 1:
+            bad = a != b
+            assert bad.float().mean().item() < 1e-4 and (a - b).abs().max().item() <= 2.0 ** -6, "gelu' differs by more than a rounding"
+        else:
+            assert torch.equal(a, b), f"output {i} of the two epilogue forms differs"
+
+
 @pytest.mark.parametrize("layout,epi,cdt", [("nt", "res", torch.bfloat16), ("nt", "res", torch.float32), ("nn", "store", torch.bfloat16),
                                             ("nt", "store", torch.bfloat16)])
 def test_gemm_tail_fixup_by_the_last_arriving_slice(ops, lib, layout, epi, cdt):

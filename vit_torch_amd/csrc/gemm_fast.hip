@@ -864,7 +864,27 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
       }
       if constexpr (SPLITK)
         storev<float, W>(ws + row_off((int64_t)split * pM + m0 + wm * 128 + mi * 16 + j * RPI, rr, pN, ncol), v);
-      else {
+      else if constexpr (MODE == VITMI_EPI_BIAS_GELU && DEEP == 2 && W == 8) {
+        // the fc1 epilogue of the bf16 step as straight-line code: gelu and gelu' of acc + bias, both stored `nt`
+        // (the general row function branches on the saved-derivative / second-output / store-policy options per store)
+        bf16x8 oc, od;
+#pragma unroll
+        for (int i = 0; i < W; i += 2) {
+          f32x2 r, d;
+          gelu_both2(f32x2{v[i] + bias_r[i], v[i + 1] + bias_r[i + 1]}, &r, &d);
+          oc[i] = (bf16)r[0]; oc[i + 1] = (bf16)r[1];
+          od[i] = (bf16)d[0]; od[i + 1] = (bf16)d[1];
+        }
+        const int64_t mu = m0 + wm * 128 + mi * 16 + j * RPI;
+        __builtin_nontemporal_store(od, reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(g.e.C2) + row_off(mu, rr, g.e.ldc2, ncol)));
+        __builtin_nontemporal_store(oc, reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(g.e.C) + row_off(mu, rr, g.e.ldc, ncol)));
+      } else if constexpr (MODE == VITMI_EPI_STORE && DEEP == 2 && W == 8) {
+        // plain bf16 output (alpha = 1, nothing accumulated), `nt` store: qkv forward and the data gradients of the step
+        bf16x8 oc;
+#pragma unroll
+        for (int i = 0; i < W; ++i) oc[i] = (bf16)(v[i] + bias_r[i]);
+        __builtin_nontemporal_store(oc, reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(g.e.C) + row_off(m0 + wm * 128 + mi * 16 + j * RPI, rr, g.e.ldc, ncol)));
+      } else {
         epi_row<MODE, TC, W>(g.e, m0 + wm * 128 + mi * 16 + j * RPI, rr, ncol, v, bias_r, gamma_r, sx[mi & 1][j]);
         if constexpr (MODE == VITMI_EPI_DGELU) {
 #pragma unroll
@@ -1167,6 +1187,9 @@ int launch_p(const GemmArgs& g_in, hipStream_t stream) {
       const int full = nwg - rem;
       constexpr bool CAN_DEEP = sizeof(TC) == 2 && (MODE == VITMI_EPI_RESIDUAL || MODE == VITMI_EPI_DGELU);
       auto kmain = gemm_fast_kernel<A_KM, B_KM, MODE, TC, false, PIPE>;
+      if constexpr (MODE == VITMI_EPI_STORE && sizeof(TC) == 2) {
+        if (g.side_depth >= 3 && g.e.alpha == 1.f && !g.e.accumulate && g.e.c_policy == 2) kmain = gemm_fast_kernel<A_KM, B_KM, MODE, TC, false, PIPE, false, 2>;
+      }
       if constexpr (CAN_DEEP) {
         if (g.side_depth >= 3) {
           kmain = gemm_fast_kernel<A_KM, B_KM, MODE, TC, false, PIPE, false, 1>;
@@ -1207,6 +1230,12 @@ int launch_p(const GemmArgs& g_in, hipStream_t stream) {
   }
   constexpr bool CAN_DEEP2 = sizeof(TC) == 2 && (MODE == VITMI_EPI_RESIDUAL || MODE == VITMI_EPI_DGELU);
   auto kern = gemm_fast_kernel<A_KM, B_KM, MODE, TC, false, PIPE>;
+  if constexpr (MODE == VITMI_EPI_BIAS_GELU && sizeof(TC) == 2) {
+    if (g.side_depth >= 3 && g.e.aux_deriv && g.e.C2 && g.e.c_policy == 2) kern = gemm_fast_kernel<A_KM, B_KM, MODE, TC, false, PIPE, false, 2>;
+  }
+  if constexpr (MODE == VITMI_EPI_STORE && sizeof(TC) == 2) {
+    if (g.side_depth >= 3 && g.e.alpha == 1.f && !g.e.accumulate && g.e.c_policy == 2) kern = gemm_fast_kernel<A_KM, B_KM, MODE, TC, false, PIPE, false, 2>;
+  }
   if constexpr (CAN_DEEP2) {
     if (g.side_depth >= 3) {
       kern = gemm_fast_kernel<A_KM, B_KM, MODE, TC, false, PIPE, false, 1>;

@@ -91,6 +91,8 @@ __device__ __forceinline__ void raw_barrier() {
 //   gelu'(x) = 0.5 + copysign(0.5 - h, x) + x e / sqrt(2 pi).
 // The fp32 parity mode (generic kernel) keeps erff.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, float b, float c) { return __builtin_elementwise_fma(a, f32x2{b, b}, f32x2{c, c}); }
 __device__ __forceinline__ void gelu_tail2(f32x2 x, f32x2* h, f32x2* e) {
   const f32x2 arg = (x * x) * -0.72134752044f;
   f32x2 ee, t;
@@ -98,10 +100,12 @@ __device__ __forceinline__ void gelu_tail2(f32x2 x, f32x2* h, f32x2* e) {
   ee[1] = __builtin_amdgcn_exp2f(arg[1]);
   t[0] = __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_fabsf(x[0]), 0.2316419f, 1.f));
   t[1] = __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_fabsf(x[1]), 0.2316419f, 1.f));
-  f32x2 p = t * 0.5307027145f + -0.7265760135f;
-  p = p * t + 0.7107068705f;
-  p = p * t + -0.142248368f;
-  p = p * t + 0.127414796f;
+  // explicit fmas: left to -ffp-contract the same source contracted differently in different epilogue variants
+  // (results one fp32 ulp apart, an occasional bf16 rounding flipped between two builds of the same formula)
+  f32x2 p = fma2(t, 0.5307027145f, -0.7265760135f);
+  p = fma2(p, t, f32x2{0.7107068705f, 0.7107068705f});
+  p = fma2(p, t, f32x2{-0.142248368f, -0.142248368f});
+  p = fma2(p, t, f32x2{0.127414796f, 0.127414796f});
   *h = (p * t) * ee;
   *e = ee;
 }
@@ -122,7 +126,7 @@ __device__ __forceinline__ void gelu_both2(f32x2 x, f32x2* gl, f32x2* dg) {
   d[0] = __builtin_copysignf(d[0], x[0]);
   d[1] = __builtin_copysignf(d[1], x[1]);
   *gl = r;
-  *dg = (d + 0.5f) + (x * e) * 0.39894228040143267794f;
+  *dg = fma2(x * e, f32x2{0.39894228040143267794f, 0.39894228040143267794f}, d + 0.5f);
 }
 __device__ __forceinline__ f32x2 dgelu2(f32x2 x) {
   f32x2 h, e;
@@ -130,7 +134,7 @@ __device__ __forceinline__ f32x2 dgelu2(f32x2 x) {
   f32x2 d = 0.5f - h;
   d[0] = __builtin_copysignf(d[0], x[0]);
   d[1] = __builtin_copysignf(d[1], x[1]);
-  return (d + 0.5f) + (x * e) * 0.39894228040143267794f;
+  return fma2(x * e, f32x2{0.39894228040143267794f, 0.39894228040143267794f}, d + 0.5f);
 }
 
 // ---- W-wide row vectors (W = 8 for bf16 outputs = 16 B, W = 4 for fp32 = 16 B)
