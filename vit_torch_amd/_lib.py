@@ -8,8 +8,11 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
+import os
+
 HERE = Path(__file__).resolve().parent
-LIB_PATH = HERE / "libvitmi.so"
+# VITMI_LIB: another build of the same library (A/B of two builds in separate processes on one box: tools/lib_ab.sh)
+LIB_PATH = Path(os.environ["VITMI_LIB"]).resolve() if os.environ.get("VITMI_LIB") else HERE / "libvitmi.so"
 
 F32, BF16 = 0, 1
 EPI_STORE, EPI_BIAS_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_PATCH_POS = 0, 1, 2, 3, 4

@@ -65,7 +65,8 @@ def _compile_one(src: str, force: bool) -> Path:
     stamp = max(s.stat().st_mtime, _newest_header(), Path(__file__).stat().st_mtime)
     if not force and o.exists() and o.stat().st_mtime >= stamp:
         return o
-    cmd = [_hipcc(), *FLAGS, "-x", "hip", "-c", str(s), "-o", str(o)]
+    extra = os.environ.get("VITMI_EXTRA_FLAGS", "").split()      # e.g. -DVITMI_GEMM_PHASE_STAMPS for tools/gemm_phases.py
+    cmd = [_hipcc(), *FLAGS, *extra, "-x", "hip", "-c", str(s), "-o", str(o)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")

@@ -422,7 +422,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
   // diagnostic build of the timeline (armed by tools/gemm_phases.py only): entry,
   // epilogue start and end of the first tile of the first blocks, wave 0
   const bool dbg_tl = g.dbg != nullptr && (int)blockIdx.x < g.dbg_blocks && wave == 0;
+  // per-phase stamps of the main loop (tools/gemm_phases.py): compiled in only with -DVITMI_GEMM_PHASE_STAMPS
+  // (VITMI_EXTRA_FLAGS of vit_torch_amd/build.py).  As a run-time option they put four scalar branches around s_memtime
+  // blocks into every slab iteration of every production launch (round 3: ISA audit of the loop).
+#ifdef VITMI_GEMM_PHASE_STAMPS
   const bool dbg = g.dbg != nullptr && blockIdx.x == 0;   // wave-uniform
+#else
+  constexpr bool dbg = false;
+#endif
   if constexpr (PERSIST) {
     if (g.zero_cnt && blockIdx.x == 0 && tid < g.zero_n) g.zero_cnt[tid] = 0u;     // the tail launch that follows counts from 0
   }
@@ -576,11 +583,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
     raw_barrier();                                 // b0
     if (grp == 1) raw_barrier();                   // stagger
     unsigned long long tR = 0, tWR = 0, tM = 0, tWM = 0, t0 = 0, t1 = 0;
-#pragma unroll 1
-    for (int j = 0; j < ns; ++j) {
+    // One slab iteration.  STEADY (j + AHEAD < ns, i.e. every iteration but the last three): the DMA of slab j + AHEAD is
+    // always issued, two younger slabs are always in flight (vmcnt(8)) and both barriers are unconditional — as
+    // compile-time facts, so the steady-state loop carries no scalar branch ladder (wait_vm's three-way switch, the
+    // issue / barrier conditions: ~10 branches per iteration in the round-2 loop).  The residual-fold loop (PIPE 3) keeps
+    // the general form for every iteration.
+    auto slab_iter = [&](int j, auto steady_tag) {
+      constexpr bool STEADY = decltype(steady_tag)::value;
       if (dbg) t0 = stamp();
       // ---- R(j)
-      if (j + AHEAD < ns) {
+      if (STEADY || j + AHEAD < ns) {
         char* st = smem + stage_of(AHEAD) * RING_STAGE;
         sa.issue(st, j + AHEAD, wave);
         sb.issue(st + SLAB_BYTES, j + AHEAD, wave);
@@ -623,13 +635,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
       // slab j+1 must have landed before the next iteration reads it: everything issued after
       // it may still be in flight = the slabs ahead of it + the strip issued in this iteration
       // or the previous one (strips go out every other iteration, behind that iteration's slab)
-      int fly = min(ns - 2 - j, AHEAD - 1);
-      if (fly < 0) fly = 0;
-      int nvm = 4 * fly;
-      // strips younger than slab j+1: the one issued in this iteration (even j in [2,16)) or the
-      // previous one (odd j), or the prologue's strip 0 (younger than slab 1 only: j = 0)
-      if constexpr (RFOLD_T) { if (rfold && (j == 0 || (j >= 2 && j < 16))) nvm += 4; }
-      if (grp == 1) wait_vm(nvm);
+      int nvm = 4 * (AHEAD - 1);
+      if constexpr (!STEADY) {
+        int fly = min(ns - 2 - j, AHEAD - 1);
+        if (fly < 0) fly = 0;
+        nvm = 4 * fly;
+        // strips younger than slab j+1: the one issued in this iteration (even j in [2,16)) or the
+        // previous one (odd j), or the prologue's strip 0 (younger than slab 1 only: j = 0)
+        if constexpr (RFOLD_T) { if (rfold && (j == 0 || (j >= 2 && j < 16))) nvm += 4; }
+      }
+      if (grp == 1) { if constexpr (STEADY) wait_vm_c<4 * (AHEAD - 1)>(); else wait_vm(nvm); }
       if (dbg) { t1 = stamp(); tR += t1 - t0; }
       raw_barrier();
       if (dbg) { t0 = stamp(); tWR += t0 - t1; }
@@ -645,12 +660,19 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
 #ifdef VITMI_GEMM_SETPRIO
       __builtin_amdgcn_s_setprio(0);
 #endif
-      if (grp == 0) wait_vm(nvm);
+      if (grp == 0) { if constexpr (STEADY) wait_vm_c<4 * (AHEAD - 1)>(); else wait_vm(nvm); }
       if (dbg) { t1 = stamp(); tM += t1 - t0; }
-      if (!(grp == 1 && j == ns - 1)) raw_barrier();
+      if (STEADY || !(grp == 1 && j == ns - 1)) raw_barrier();
       if (dbg) { t0 = stamp(); tWM += t0 - t1; }
       stage_i = stage_i == RING - 1 ? 0 : stage_i + 1;
+    };
+    int j = 0;
+    if constexpr (!RFOLD_T) {
+#pragma unroll 1
+      for (; j + AHEAD < ns; ++j) slab_iter(j, std::true_type{});
     }
+#pragma unroll 1
+    for (; j < ns; ++j) slab_iter(j, std::false_type{});
     if (dbg && lane == 0 && !prefetched) {
       g.dbg[wave * 4 + 0] = tR; g.dbg[wave * 4 + 1] = tWR;
       g.dbg[wave * 4 + 2] = tM; g.dbg[wave * 4 + 3] = tWM;
@@ -666,11 +688,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
     raw_barrier();
     if (grp == 1) raw_barrier();
     unsigned long long tR = 0, tWR = 0, tM = 0, tWM = 0, t0 = 0, t1 = 0;
-#pragma unroll 1
-    for (int j = 0; j < ns; ++j) {
+    // One 32-deep half of stage t, KH a compile-time fact: the stage pair is unrolled, so the k-half selects, the waits of
+    // the second half and the issue of the first are not branches on j & 1 any more (round 3).
+    auto half_iter = [&](int t, auto kh_tag, auto steady_tag) {
+      constexpr int kh = decltype(kh_tag)::value;
+      constexpr bool STEADY = decltype(steady_tag)::value;
       if (dbg) t0 = stamp();
-      const int t = j >> 1, kh = j & 1;
-      if (kh == 0 && t >= 1 && t + 1 < nt) {
+      if (kh == 0 && (STEADY || (t >= 1 && t + 1 < nt))) {
         char* st = smem + ((t + 1) & 1) * STAGE_BYTES;
         ta.issue(st, t + 1, wave);
         tb.issue(st + TILE_BYTES, t + 1, wave);
@@ -692,7 +716,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
       for (int ni = 0; ni < 4; ++ni) bf[ni] = fbv[ni].get();
 #pragma unroll
       for (int mi = 0; mi < 8; ++mi) af[mi] = fav[mi].get();
-      if (grp == 1 && kh == 1) wait_vm(0);
+      if (kh == 1 && grp == 1) wait_vm_c<0>();
       if (dbg) { t1 = stamp(); tR += t1 - t0; }
       raw_barrier();
       if (dbg) { t0 = stamp(); tWR += t0 - t1; }
@@ -701,10 +725,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[ni][mi], 0, 0, 0);
-      if (grp == 0 && kh == 1) wait_vm(0);
+      if (kh == 1 && grp == 0) wait_vm_c<0>();
       if (dbg) { t1 = stamp(); tM += t1 - t0; }
-      if (!(grp == 1 && j == ns - 1)) raw_barrier();
+      if (STEADY || kh == 0 || !(grp == 1 && t == nt - 1)) raw_barrier();
       if (dbg) { t0 = stamp(); tWM += t0 - t1; }
+    };
+#pragma unroll 1
+    for (int t = 0; t < nt; ++t) {                   // (a steady-state copy of the pair, as in the ring loop, made hipcc spill here)
+      half_iter(t, std::integral_constant<int, 0>{}, std::false_type{});
+      half_iter(t, std::integral_constant<int, 1>{}, std::false_type{});
     }
     if (dbg && lane == 0 && !prefetched) {
       g.dbg[wave * 4 + 0] = tR; g.dbg[wave * 4 + 1] = tWR;
