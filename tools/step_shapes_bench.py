@@ -58,6 +58,15 @@ A0, B0, C0 = rnd(M, 768), rnd(M, 768), torch.empty(768, 768, device=dev)
 A1, B1, C1 = rnd(M, 2304), rnd(M, 768), torch.empty(2304, 768, device=dev)
 cases.append(("tn proj + qkv wgrad (pair)      ", 2.0 * M * 768 * (768 + 2304), lambda: ops.gemm_pair(A0, B0, C0, A1, B1, C1)))
 
+import ctypes  # noqa: E402
+raw = ctypes.CDLL(str(_lib.LIB_PATH))
+qkv = cases[0]
+for pm in (1, 2):                                     # the qkv forward on the other main loops (default: the two-stage loop, PIPE 0)
+    def forced(pm=pm, f=qkv[2]):
+        raw.vitmi_debug_gemm_pipe(pm)
+        f()
+        raw.vitmi_debug_gemm_pipe(-1)
+    cases.append((f"nt qkv fwd, loop {pm} forced       ", qkv[1], forced))
 tag = os.path.basename(str(_lib.LIB_PATH))
 tot = 0.0
 for rnd_i in range(2):
@@ -67,4 +76,4 @@ for rnd_i in range(2):
         tot += us
         if rnd_i == 1:
             print(f"{tag:18s} {name} {us:7.1f} us  {fl / us / 1e6:7.1f} TFLOP/s", flush=True)
-print(f"{tag:18s} block total {tot:8.1f} us")
+print(f"{tag:18s} block total (incl. the two extra qkv lines) {tot:8.1f} us")

@@ -120,11 +120,18 @@ template <bool KM> struct SlabPlan {
       step = 64 * ld;
     }
   }
+  // the same from a wave-uniform LDS byte address (ring iterations unrolled over the stages)
+  __device__ __forceinline__ void issue_addr(uint32_t lds_addr, int j) const {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16_sbase_m0(base[i] + (int64_t)j * step, off[i], lds_addr + i * 1024);
+  }
   template <bool HID = false>
   __device__ __forceinline__ void issue(char* slab, int j, int wave) const {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      glds16x<HID>(base[i] + (int64_t)j * step + off[i], slab + (wave * 2 + i) * 1024);
+    for (int i = 0; i < 2; ++i) {
+      if constexpr (HID) glds16_sbase(base[i] + (int64_t)j * step, off[i], slab + (wave * 2 + i) * 1024);
+      else glds16(base[i] + (int64_t)j * step + off[i], slab + (wave * 2 + i) * 1024);
+    }
   }
 };
 
@@ -177,8 +184,10 @@ template <bool KM> struct StagePlan {
   template <bool HID = false>
   __device__ __forceinline__ void issue(char* tile, int t, int wave) const {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      glds16x<HID>(base[i] + (int64_t)t * step + off[i], tile + (wave * 4 + i) * 1024);
+    for (int i = 0; i < 4; ++i) {
+      if constexpr (HID) glds16_sbase(base[i] + (int64_t)t * step, off[i], tile + (wave * 4 + i) * 1024);
+      else glds16(base[i] + (int64_t)t * step + off[i], tile + (wave * 4 + i) * 1024);
+    }
   }
 };
 // per-lane LDS byte offset (k-half 0) of the fragment of block rb in a 64-deep stage
@@ -246,7 +255,10 @@ struct ResFold {
   template <bool HID = false>
   __device__ __forceinline__ void issue(char* strip, int s) const {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16x<HID>(base + (int64_t)s * strip_step + off[i], strip + i * 1024);
+    for (int i = 0; i < 4; ++i) {
+      if constexpr (HID) glds16_sbase(base + (int64_t)s * strip_step, off[i], strip + i * 1024);
+      else glds16(base + (int64_t)s * strip_step + off[i], strip + i * 1024);
+    }
   }
   // the wave's accumulator-shaped view of the strip: f32x4 of (row lr, columns 16 ni + 4 lg ..)
   __device__ __forceinline__ void read(const char* strip, u32x4 (&r)[4]) const {
@@ -464,6 +476,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) fb[ni] = frag_off64<B_KM>(wn * 4 + ni, lane);
   }
+  const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
+  uint32_t fa_lo[8], fa_hi[8], fb_lo[4], fb_hi[4];   // PIPE 1: LDS byte addresses of the fragments in stage 0 / stage 2 (see slab_iter)
+  constexpr bool STAGE_UNROLL = PIPE == 1 && SPLITK && !(A_KM && !B_KM);   // (the NN split-K form spills with the second address set)
+  if constexpr (STAGE_UNROLL) {
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) { fa_lo[mi] = lds0 + fa[mi]; fa_hi[mi] = fa_lo[mi] + 2 * RING_STAGE; }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) { fb_lo[ni] = lds0 + fb[ni]; fb_hi[ni] = fb_lo[ni] + 2 * RING_STAGE; }
+  }
   char* rstrip = smem + RF_BASE + wave * 2 * RF_STRIP;   // PIPE 3: this wave's two residual strip buffers
   // epilogue strip: above the stages (the stages may already be receiving the next tile)
   // (split-K launches own only the two stages' 128 KiB and have no prefetch in flight after the loop: their strips alias the
@@ -477,7 +498,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
   // hid (a std::bool_constant): the DMAs go out from inline asm, unseen by hipcc — the prologue issued in front of an
   // epilogue (glds16_hidden)
   auto start_tile = [&](int64_t m0, int64_t n0, auto hid) {
-    constexpr bool HID = decltype(hid)::value;
+    constexpr bool HID = decltype(hid)::value || PIPE != 0;     // the phased loops wait and order every DMA themselves: all of theirs go out unseen
     if constexpr (RINGP) {
       sa.init(A, lda, m0, kb0, wave, lane);
       sb.init(B, ldb, n0, kb0, wave, lane);
@@ -588,22 +609,39 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
     // compile-time facts, so the steady-state loop carries no scalar branch ladder (wait_vm's three-way switch, the
     // issue / barrier conditions: ~10 branches per iteration in the round-2 loop).  The residual-fold loop (PIPE 3) keeps
     // the general form for every iteration.
-    auto slab_iter = [&](int j, auto steady_tag) {
+    // STAGE >= 0 (steady iterations of the four-stage ring, unrolled over the stages): the stage of slab j is a
+    // compile-time fact, so the fragment reads take it as an IMMEDIATE offset from one of two per-lane address sets
+    // (stages 0 / 1: the address itself, + 32 KiB; stages 2 / 3: address + 64 KiB, + 32 KiB) and the DMA destination is a
+    // constant: the twelve per-fragment address adds and the ring arithmetic leave the R phase (ISA audit, round 3).
+    auto slab_iter = [&](int j, auto steady_tag, auto stage_tag) {
       constexpr bool STEADY = decltype(steady_tag)::value;
+      constexpr int STAGE = decltype(stage_tag)::value;
       if (dbg) t0 = stamp();
       // ---- R(j)
-      if (STEADY || j + AHEAD < ns) {
-        char* st = smem + stage_of(AHEAD) * RING_STAGE;
-        sa.issue(st, j + AHEAD, wave);
-        sb.issue(st + SLAB_BYTES, j + AHEAD, wave);
-      }
-      const char* As = smem + stage_i * RING_STAGE;
       Frag<B_KM> fbv[4];
       Frag<A_KM> fav[8];
+      if constexpr (STAGE >= 0) {
+        constexpr int DST = (STAGE + AHEAD) % RING;
+        const uint32_t da = lds0 + DST * RING_STAGE + wave * 2048;
+        sa.issue_addr(da, j + AHEAD);
+        sb.issue_addr(da + SLAB_BYTES, j + AHEAD);
+        constexpr int IMM = (STAGE & 1) * RING_STAGE;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) fbv[ni].template load_imm<IMM>(STAGE < 2 ? fb_lo[ni] : fb_hi[ni]);
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) fav[mi].template load_imm<IMM>(STAGE < 2 ? fa_lo[mi] : fa_hi[mi]);
+      } else {
+      if (STEADY || j + AHEAD < ns) {
+        char* st = smem + stage_of(AHEAD) * RING_STAGE;
+        sa.template issue<true>(st, j + AHEAD, wave);
+        sb.template issue<true>(st + SLAB_BYTES, j + AHEAD, wave);
+      }
+      const char* As = smem + stage_i * RING_STAGE;
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) fbv[ni].load(As, fb[ni]);
 #pragma unroll
       for (int mi = 0; mi < 8; ++mi) fav[mi].load(As, fa[mi]);
+      }
       // residual fold: strip s is issued in iteration 2s (s = 0 in the prologue) and read in
       // iteration 2s + 4; buffer s & 1
       u32x4 rfv[4];
@@ -625,7 +663,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
               for (int ni = 0; ni < 4; ++ni) acc[ni][S] += __builtin_bit_cast(f32x4, rfv[ni]);
             }
         }
-        if (rf_issue) rf.issue(rstrip + ((j >> 1) & 1) * RF_STRIP, j >> 1);   // its buffer has just been read
+        if (rf_issue) rf.template issue<true>(rstrip + ((j >> 1) & 1) * RF_STRIP, j >> 1);   // its buffer has just been read
       }
       bf16x8 bf[4], af[8];
 #pragma unroll
@@ -664,15 +702,27 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
       if (dbg) { t1 = stamp(); tM += t1 - t0; }
       if (STEADY || !(grp == 1 && j == ns - 1)) raw_barrier();
       if (dbg) { t0 = stamp(); tWM += t0 - t1; }
-      stage_i = stage_i == RING - 1 ? 0 : stage_i + 1;
+      if constexpr (STAGE < 0) stage_i = stage_i == RING - 1 ? 0 : stage_i + 1;
     };
+    using RT = std::integral_constant<int, -1>;
     int j = 0;
-    if constexpr (!RFOLD_T) {
+    if constexpr (!RFOLD_T && RING == 4 && STAGE_UNROLL) {
+      // four steady iterations per trip (all of j .. j + 3 have j + AHEAD < ns); the ring is back at stage 0 afterwards.
+      // Only the split-K instantiations (the weight gradients: 113-step slices, a raw-store epilogue): the twelve extra
+      // address registers make the kernels with a real epilogue spill inside the loop.
 #pragma unroll 1
-      for (; j + AHEAD < ns; ++j) slab_iter(j, std::true_type{});
+      for (; j + 3 + AHEAD < ns; j += 4) {
+        slab_iter(j, std::true_type{}, std::integral_constant<int, 0>{});
+        slab_iter(j + 1, std::true_type{}, std::integral_constant<int, 1>{});
+        slab_iter(j + 2, std::true_type{}, std::integral_constant<int, 2>{});
+        slab_iter(j + 3, std::true_type{}, std::integral_constant<int, 3>{});
+      }
+    } else if constexpr (!RFOLD_T) {
+#pragma unroll 1
+      for (; j + AHEAD < ns; ++j) slab_iter(j, std::true_type{}, RT{});
     }
 #pragma unroll 1
-    for (; j < ns; ++j) slab_iter(j, std::false_type{});
+    for (; j < ns; ++j) slab_iter(j, std::false_type{}, RT{});
     if (dbg && lane == 0 && !prefetched) {
       g.dbg[wave * 4 + 0] = tR; g.dbg[wave * 4 + 1] = tWR;
       g.dbg[wave * 4 + 2] = tM; g.dbg[wave * 4 + 3] = tWM;
@@ -696,8 +746,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
       if (dbg) t0 = stamp();
       if (kh == 0 && (STEADY || (t >= 1 && t + 1 < nt))) {
         char* st = smem + ((t + 1) & 1) * STAGE_BYTES;
-        ta.issue(st, t + 1, wave);
-        tb.issue(st + TILE_BYTES, t + 1, wave);
+        ta.template issue<true>(st, t + 1, wave);
+        tb.template issue<true>(st + TILE_BYTES, t + 1, wave);
       }
       const char* At = smem + (t & 1) * STAGE_BYTES;
       const char* Bt = At + TILE_BYTES;
@@ -1129,7 +1179,8 @@ int launch(const GemmArgs& g, hipStream_t stream) {
     // the plain-store forward with a short contraction (qkv: K = 768) runs best on the simple two-stage
     // loop: 189 -> 175 us inside the ViT-B/16 step (A/B of the three loops in one process); with an
     // epilogue that reads or computes (GELU, residual) or K = 3072 the phased loops win
-    if (A_KM && B_KM && MODE == VITMI_EPI_STORE && sizeof(TC) == 2 && g.K <= 1024) pm = 0;
+    // (round 3: with the k-half unrolled and the DMAs in the SGPR-base form the phased loop wins here too —
+    // 160-166 us against 169-171 for the qkv forward, one process — so nothing selects the two-stage loop by default)
     // the fp32-stream residual epilogue takes the ring-of-three loop that streams R through LDS
     if (CAN_FOLD && g_rfold_override != 0 && !g.e.gamma && !g.e.rowscale && !g.e.C2 && !g.e.r_bf16 && g.K >= 640) pm = 3;
   }

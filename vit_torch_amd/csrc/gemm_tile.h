@@ -22,6 +22,20 @@ __device__ __forceinline__ void glds16_hidden(const void* gsrc, char* lds_dst) {
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(l) : "memory");
 }
+// ... and in the SGPR-base + 32-bit-VGPR-offset form: the staging plans keep a wave-uniform base pointer and a per-lane
+// 32-bit offset for exactly this, but through the builtin hipcc adds them into a 64-bit VGPR address for every DMA
+// (a v_lshl_add_u64 per instruction in the R phase of every slab)
+__device__ __forceinline__ void glds16_sbase(const char* sbase, uint32_t voff, char* lds_dst) {
+  unsigned keep;
+  const unsigned l = (unsigned)(uintptr_t)LDS_PTR(char, lds_dst);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(l) : "memory");
+}
+// ... with M0 left as written: only for kernels in which EVERY LDS-DMA is one of these statements (the phased GEMM loops:
+// hipcc then has no use of M0 of its own to protect; two scalar moves less per DMA in the R phase)
+__device__ __forceinline__ void glds16_sbase_m0(const char* sbase, uint32_t voff, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
 template <bool HID> __device__ __forceinline__ void glds16x(const void* gsrc, char* lds_dst) {
   if constexpr (HID) glds16_hidden(gsrc, lds_dst);
   else glds16(gsrc, lds_dst);
@@ -41,6 +55,12 @@ template <> struct Frag<true> {
   __device__ __forceinline__ void load(const char* slab, uint32_t off) {
     v = *reinterpret_cast<const bf16x8*>(slab + off);
   }
+  // the same read at LDS byte address `addr` + IMM, IMM a compile-time constant that goes into the instruction's 16-bit
+  // offset field (the stage of an unrolled ring iteration: no per-fragment address add)
+  template <int IMM> __device__ __forceinline__ void load_imm(uint32_t addr) {
+    static_assert(IMM >= 0 && IMM < 65536, "DS offset field");
+    v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __attribute__((address_space(3))) char*>((uintptr_t)addr) + IMM);
+  }
   __device__ __forceinline__ bf16x8 get() const { return v; }
 };
 template <> struct Frag<false> {
@@ -49,6 +69,11 @@ template <> struct Frag<false> {
     const uint32_t a = (uint32_t)(uintptr_t)LDS_PTR(char, slab) + off;
     asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:2048"
                  : "=&v"(lo), "=&v"(hi) : "v"(a) : "memory");
+  }
+  template <int IMM> __device__ __forceinline__ void load_imm(uint32_t addr) {
+    static_assert(IMM >= 0 && IMM + 2048 < 65536, "DS offset field");
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+                 : "=&v"(lo), "=&v"(hi) : "v"(addr), "n"(IMM), "n"(IMM + 2048) : "memory");
   }
   __device__ __forceinline__ bf16x8 get() const {
     const u32x4 r = {lo[0], lo[1], hi[0], hi[1]};
