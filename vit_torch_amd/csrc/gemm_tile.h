@@ -59,7 +59,9 @@ template <> struct Frag<true> {
   // offset field (the stage of an unrolled ring iteration: no per-fragment address add)
   template <int IMM> __device__ __forceinline__ void load_imm(uint32_t addr) {
     static_assert(IMM >= 0 && IMM < 65536, "DS offset field");
-    v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __attribute__((address_space(3))) char*>((uintptr_t)addr) + IMM);
+    typedef __attribute__((address_space(3))) char lds_char;
+    typedef __attribute__((address_space(3))) bf16x8 lds_bf16x8;
+    v = *reinterpret_cast<const lds_bf16x8*>(reinterpret_cast<const lds_char*>((uintptr_t)addr) + IMM);
   }
   __device__ __forceinline__ bf16x8 get() const { return v; }
 };
