@@ -151,3 +151,17 @@ def test_short_gemm_descriptor_is_rejected(lib):
     d.struct_size = 232              # the layout that ended at workspace_bytes
     assert lib.vitmi_gemm(ctypes.byref(d), None) == -1
     assert b"struct_size" in lib.vitmi_last_error_string()
+
+
+def test_gemm_kernels_keep_their_accumulators_in_registers(lib):
+    """hipcc's resource remarks of the build: no gemm_fast_kernel instantiation may own more than a few spilled dwords
+    of scratch.  A comparison chain over an unrolled accumulator index once came back as a dynamically indexed array
+    (24 accumulator quads = 400 B of scratch in the fp32-residual fold loop): numerically identical, 10 x slower."""
+    from vit_torch_amd import build
+    build.build()
+    res = build.kernel_resources("gemm_fast.hip")
+    kernels = {k: v for k, v in res.items() if "gemm_fast_kernel" in k}
+    assert len(kernels) > 40
+    for name, r in kernels.items():
+        assert int(r["ScratchSize [bytes/lane]"]) <= 192, (name, r["ScratchSize [bytes/lane]"])
+        assert int(r["Occupancy [waves/SIMD]"]) >= 2, name

@@ -66,11 +66,39 @@ def _compile_one(src: str, force: bool) -> Path:
     if not force and o.exists() and o.stat().st_mtime >= stamp:
         return o
     extra = os.environ.get("VITMI_EXTRA_FLAGS", "").split()      # e.g. -DVITMI_GEMM_PHASE_STAMPS for tools/gemm_phases.py
-    cmd = [_hipcc(), *FLAGS, *extra, "-x", "hip", "-c", str(s), "-o", str(o)]
+    remarks = ["-Rpass-analysis=kernel-resource-usage"] if src.endswith(".hip") else []
+    cmd = [_hipcc(), *FLAGS, *extra, *remarks, "-x", "hip", "-c", str(s), "-o", str(o)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
+    if remarks:
+        _save_resources(src, r.stderr)
     return o
+
+
+def _save_resources(src: str, stderr: str) -> None:
+    """Per-kernel register / scratch / LDS figures of one source, from hipcc's resource-usage remarks ->
+    csrc/_obj/<src>.resources.json (tests/test_abi_cpu.py bounds the scratch of the GEMM kernels: a dynamically indexed
+    accumulator array shows up there, not in any numerical test)."""
+    import json
+    import re
+    out, cur = {}, None
+    for line in stderr.splitlines():
+        m = re.search(r"remark:\s+(.*?) \[-Rpass", line)
+        if not m or ":" not in m.group(1):
+            continue
+        k, v = (t.strip() for t in m.group(1).split(":", 1))
+        if k == "Function Name":
+            cur = out.setdefault(v, {})
+        elif cur is not None:
+            cur[k] = v
+    (OBJ / (src + ".resources.json")).write_text(json.dumps(out, indent=0))
+
+
+def kernel_resources(src: str) -> dict:
+    """{mangled kernel name: {"VGPRs": "..", "ScratchSize [bytes/lane]": "..", ...}} of the last build of `src`."""
+    import json
+    return json.loads((OBJ / (src + ".resources.json")).read_text())
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:

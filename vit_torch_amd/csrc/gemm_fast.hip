@@ -613,9 +613,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
     // compile-time fact, so the fragment reads take it as an IMMEDIATE offset from one of two per-lane address sets
     // (stages 0 / 1: the address itself, + 32 KiB; stages 2 / 3: address + 64 KiB, + 32 KiB) and the DMA destination is a
     // constant: the twelve per-fragment address adds and the ring arithmetic leave the R phase (ISA audit, round 3).
-    auto slab_iter = [&](int j, auto steady_tag, auto stage_tag) {
+    // RFS >= 0 (residual fold): this iteration adds strip RFS — a COMPILE-TIME index into the accumulators.  As a run-time
+    // comparison chain (`if ((j >> 1) - 2 == S)` over the unrolled S) hipcc recognised acc[ni][(j >> 1) - 2], put 24
+    // accumulator quads into scratch and indexed them dynamically: 2.4 ms per launch instead of 0.13-0.25.
+    auto slab_iter = [&](int j, auto steady_tag, auto stage_tag, auto rf_tag) {
       constexpr bool STEADY = decltype(steady_tag)::value;
       constexpr int STAGE = decltype(stage_tag)::value;
+      constexpr int RFS = decltype(rf_tag)::value;
       if (dbg) t0 = stamp();
       // ---- R(j)
       Frag<B_KM> fbv[4];
@@ -646,22 +650,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
       // iteration 2s + 4; buffer s & 1
       u32x4 rfv[4];
       const bool rf_even = RFOLD_T && rfold && (j & 1) == 0;                 // wave-uniform
-      const bool rf_read = rf_even && j >= 4 && j < 20;
       const bool rf_issue = rf_even && j >= 2 && j < 16;
-      if constexpr (RFOLD_T) { if (rf_read) rf.read(rstrip + (((j >> 1) - 2) & 1) * RF_STRIP, rfv); }
+      if constexpr (RFOLD_T && RFS >= 0) rf.read(rstrip + (RFS & 1) * RF_STRIP, rfv);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of this stage are complete
       frag_wait4(fbv[0], fbv[1], fbv[2], fbv[3]);
       frag_wait4(fav[0], fav[1], fav[2], fav[3]);
       frag_wait4(fav[4], fav[5], fav[6], fav[7]);
       if constexpr (RFOLD_T) {
-        if (rf_read) {
+        if constexpr (RFS >= 0) {
           asm volatile("" : "+v"(rfv[0]), "+v"(rfv[1]), "+v"(rfv[2]), "+v"(rfv[3]));   // named after the wait
 #pragma unroll
-          for (int S = 0; S < 8; ++S)
-            if ((j >> 1) - 2 == S) {
-#pragma unroll
-              for (int ni = 0; ni < 4; ++ni) acc[ni][S] += __builtin_bit_cast(f32x4, rfv[ni]);
-            }
+          for (int ni = 0; ni < 4; ++ni) acc[ni][RFS] += __builtin_bit_cast(f32x4, rfv[ni]);
         }
         if (rf_issue) rf.template issue<true>(rstrip + ((j >> 1) & 1) * RF_STRIP, j >> 1);   // its buffer has just been read
       }
@@ -705,6 +704,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
       if constexpr (STAGE < 0) stage_i = stage_i == RING - 1 ? 0 : stage_i + 1;
     };
     using RT = std::integral_constant<int, -1>;
+    using NRF = std::integral_constant<int, -1>;
     int j = 0;
     if constexpr (!RFOLD_T && RING == 4 && STAGE_UNROLL) {
       // four steady iterations per trip (all of j .. j + 3 have j + AHEAD < ns); the ring is back at stage 0 afterwards.
@@ -712,17 +712,33 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
       // address registers make the kernels with a real epilogue spill inside the loop.
 #pragma unroll 1
       for (; j + 3 + AHEAD < ns; j += 4) {
-        slab_iter(j, std::true_type{}, std::integral_constant<int, 0>{});
-        slab_iter(j + 1, std::true_type{}, std::integral_constant<int, 1>{});
-        slab_iter(j + 2, std::true_type{}, std::integral_constant<int, 2>{});
-        slab_iter(j + 3, std::true_type{}, std::integral_constant<int, 3>{});
+        slab_iter(j, std::true_type{}, std::integral_constant<int, 0>{}, NRF{});
+        slab_iter(j + 1, std::true_type{}, std::integral_constant<int, 1>{}, NRF{});
+        slab_iter(j + 2, std::true_type{}, std::integral_constant<int, 2>{}, NRF{});
+        slab_iter(j + 3, std::true_type{}, std::integral_constant<int, 3>{}, NRF{});
       }
     } else if constexpr (!RFOLD_T) {
 #pragma unroll 1
-      for (; j + AHEAD < ns; ++j) slab_iter(j, std::true_type{}, RT{});
+      for (; j + AHEAD < ns; ++j) slab_iter(j, std::true_type{}, RT{}, NRF{});
+    } else {
+      // residual fold (ns >= 20): slabs 0-3 in the general form, then strip S is added in iteration 4 + 2 S
+      if (rfold) {
+#pragma unroll 1
+        for (; j < 4; ++j) slab_iter(j, std::false_type{}, RT{}, NRF{});
+        auto rf_pair = [&](auto s_tag) {
+          constexpr int S = decltype(s_tag)::value;
+          slab_iter(4 + 2 * S, std::false_type{}, RT{}, s_tag);
+          slab_iter(5 + 2 * S, std::false_type{}, RT{}, NRF{});
+        };
+        rf_pair(std::integral_constant<int, 0>{}); rf_pair(std::integral_constant<int, 1>{});
+        rf_pair(std::integral_constant<int, 2>{}); rf_pair(std::integral_constant<int, 3>{});
+        rf_pair(std::integral_constant<int, 4>{}); rf_pair(std::integral_constant<int, 5>{});
+        rf_pair(std::integral_constant<int, 6>{}); rf_pair(std::integral_constant<int, 7>{});
+        j = 20;
+      }
     }
 #pragma unroll 1
-    for (; j < ns; ++j) slab_iter(j, std::false_type{}, RT{});
+    for (; j < ns; ++j) slab_iter(j, std::false_type{}, RT{}, NRF{});
     if (dbg && lane == 0 && !prefetched) {
       g.dbg[wave * 4 + 0] = tR; g.dbg[wave * 4 + 1] = tWR;
       g.dbg[wave * 4 + 2] = tM; g.dbg[wave * 4 + 3] = tWM;
