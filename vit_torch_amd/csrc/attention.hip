@@ -110,6 +110,33 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int base) {
   return r;
 }
 
+// max of three in ONE instruction.  fmaxf() under the kernel's IEEE mode costs a canonicalising `v_max_f32 x, x, x` per
+// operand that comes from an MFMA (hipcc cannot prove it is not a signalling NaN): 28 instructions for the 16-score row
+// maximum of the forward's key block, 8 with these.
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float max16(const f32x16& s) {
+  const float t0 = max3f(s[0], s[1], s[2]), t1 = max3f(s[3], s[4], s[5]), t2 = max3f(s[6], s[7], s[8]);
+  const float t3 = max3f(s[9], s[10], s[11]), t4 = max3f(s[12], s[13], s[14]);
+  return max3f(max3f(t0, t1, t2), max3f(t3, t4, s[15]), t0);
+}
+// p = exp2(s * c - m) for the 16 scores of a lane, in place, and their sum.  (Round 3 tried the scale-and-shift and the sum on
+// packed fp32 instructions — v_pk_fma_f32 / v_pk_add_f32, 8 + 8 instead of 16 + 16: forward 88-94 -> 92-99 us per ViT-B/16
+// layer, and the same idea in the fused backward's loop 17.9 k -> 18.8 k cycles.  Packed VALU beside MFMAs is an anti-lever.)
+__device__ __forceinline__ float exp2_scaled_sum16(f32x16& s, float c, float m) {
+  float psum = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c, -m));
+    s[r] = p;
+    psum += p;
+  }
+  return psum;
+}
+
 __device__ __forceinline__ void zero16(f32x16& v) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) v[r] = 0.f;
@@ -379,10 +406,8 @@ __global__ __launch_bounds__(512) void attn_fwd_whole_kernel(const bf16* __restr
       for (int r = 0; r < 16; ++r)
         if (key0 + mfma32_row(r, h5) >= N) s[r] = -INFINITY;
     }
-    float tmax = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
-#pragma unroll
-    for (int r = 4; r < 16; r += 2) tmax = fmaxf(tmax, fmaxf(s[r], s[r + 1]));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    float tmax = max16(s);
+    tmax = max3f(tmax, __shfl_xor(tmax, 32), tmax);
     const float m_new = fmaxf(m, tmax * scale_log2e);
     if (!__all(m_new == m)) {                  // some row's max moved: rescale once
       const float alpha = __builtin_amdgcn_exp2f(m - m_new);
@@ -393,13 +418,7 @@ __global__ __launch_bounds__(512) void attn_fwd_whole_kernel(const bf16* __restr
         for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
       m = m_new;
     }
-    float psum = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float p = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -m));
-      s[r] = p;
-      psum += p;
-    }
+    const float psum = exp2_scaled_sum16(s, scale_log2e, m);
     l += psum + __shfl_xor(psum, 32);
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
@@ -891,6 +910,8 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = kvalid ? s[r] : 0.f;
     }
+    // (round 3: the same arithmetic on packed fp32 instructions — v_pk_fma / v_pk_add / v_pk_mul, 24 instead of 48 per
+    // step — measured SLOWER: loop 17.9 k -> 18.8 k cycles, 217 -> 224 us per layer; packed VALU beside MFMAs is an anti-lever)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
 #pragma unroll
