@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VITMI_VERSION 105
+#define VITMI_VERSION 106
 
 enum { VITMI_F32 = 0, VITMI_BF16 = 1 };
 
@@ -181,6 +181,32 @@ int vitmi_layernorm_bwd(const void* dy, int dy_dtype, int64_t dy_stride,
                         const float* gb_rowscale, int64_t rows_per_group,
                         int64_t M, int64_t D,
                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same pass with the fold of its partial sums left to the caller (ABI 106): the per-workgroup partial rows of
+ * dgamma | dbeta | gsum stay in `workspace` — which the caller must then keep untouched until the fold has run — and
+ * *fold describes them for vitmi_fold_many.  A training step queues these (and the bias partials of the GEMM / attention
+ * epilogues) and folds a whole backward pass, or one gradient-bucket section, in one launch.  vitmi_layernorm_bwd is
+ * this call followed by vitmi_fold_many(fold, 1). */
+typedef struct vitmi_fold_desc {
+  int64_t struct_size;   /* = sizeof(vitmi_fold_desc) */
+  const float* part;     /* fp32 [S][ld] partial sums */
+  int32_t S;             /* partial rows */
+  int32_t nseg;          /* 1..3 segments of N consecutive columns in a row */
+  int64_t N, ld;
+  float* out[3];         /* fp32 [N] per segment, overwritten with the column sums over the S rows */
+} vitmi_fold_desc;
+int vitmi_layernorm_bwd_deferred(const void* dy, int dy_dtype, int64_t dy_stride,
+                                 const void* x, int x_dtype, int64_t x_stride,
+                                 const float* mean, const float* rstd, const float* gamma,
+                                 const void* g_in, void* g_out, int g_dtype, int64_t g_stride,
+                                 void* gb_out, int gb_dtype, int64_t gb_stride,
+                                 float* dgamma, float* dbeta, float* gsum, const float* gb_scale,
+                                 const float* gb_rowscale, int64_t rows_per_group,
+                                 int64_t M, int64_t D,
+                                 void* workspace, size_t workspace_bytes, vitmi_fold_desc* fold, void* stream);
+/* n folds (host array) in ceil(n / 32) launches; each output column is summed over its S rows in the same fixed order as
+ * by the single-fold calls (bit-identical, deterministic). */
+int vitmi_fold_many(const vitmi_fold_desc* descs, int n, void* stream);
 
 /* ------------------------------------------------------------ Attention --
  * Multi-head self-attention core: softmax(scale * q k^T) v, fused (scores

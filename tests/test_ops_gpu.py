@@ -1009,3 +1009,51 @@ def test_gemm_tail_fixup_by_the_last_arriving_slice(ops, lib, layout, epi, cdt):
     assert_close("tail fix-up", outs[0], want, 1e-4 if cdt == torch.float32 else TOL[bt])
     for o in outs[1:]:
         assert torch.equal(outs[0], o), "fix-up by the last slice and the finisher kernel must agree bit for bit"
+
+
+# ------------------------------------------------------- deferred folds ---
+def test_fold_many_equals_the_single_folds_bitwise(ops):
+    """vitmi_fold_many: 40 queued folds of mixed shapes (more than one 32-entry launch), one to three segments each,
+    against the one-launch-per-fold calls: every output bit-identical."""
+    q = ops.FoldQueue()
+    want, got = [], []
+    for i in range(40):
+        S, N, nseg = [7, 64, 394, 1500][i % 4], [10, 96, 768, 2304, 33][i % 5], 1 + i % 3
+        part = dev(gen((S, nseg * N + (8 if i % 2 else 0)), 100 + i))
+        ld = part.shape[1]
+        ref = [torch.empty(N, device="cuda") for _ in range(nseg)]
+        for k in range(nseg):
+            ops.colsum(part[:, k * N:], ref[k], M=S, N=N, ld=ld)
+        outs = [torch.full((N,), float("nan"), device="cuda") for _ in range(nseg)]
+        q.add(part, S, N, ld, outs)
+        want.append(ref)
+        got.append(outs)
+    assert len(q) == 40
+    q.flush()
+    assert len(q) == 0
+    torch.cuda.synchronize()
+    for ref, outs in zip(want, got):
+        for r, o in zip(ref, outs):
+            assert torch.equal(r, o)
+        assert_close("fold", outs[0], ref[0], 0.0)
+
+
+@pytest.mark.parametrize("M,D,T,R", [(394, 768, torch.bfloat16, torch.bfloat16), (1030, 96, torch.bfloat16, torch.float32),
+                                     (77, 384, torch.float32, torch.float32)])
+def test_layernorm_bwd_deferred_fold_equals_the_immediate_one(ops, M, D, T, R):
+    x, dy, gin = dev(gen((M, D), 1) * 1.5 + 0.3, R), dev(gen((M, D), 2), T), dev(gen((M, D), 3), R)
+    g = dev(1 + 0.1 * gen((D,), 4))
+    mean, rstd = x.float().mean(-1), (x.float().var(-1, unbiased=False) + 1e-6).rsqrt()
+    res = []
+    for q in (None, ops.FoldQueue()):
+        G = gin.clone()
+        Gb = torch.empty((M, D), device="cuda", dtype=T) if T != R else None
+        dg, db, gs = (torch.full((D,), float("nan"), device="cuda") for _ in range(3))
+        ops.layernorm_bwd(dy, x, mean, rstd, g, G, G, Gb, dg, db, gsum=gs, fold=q)
+        if q is not None:
+            ops.workspace(1 << 20, x.device).fill_(0x7f)      # the deferred partials do not live in the shared workspace
+            q.flush()
+        res.append((G, dg, db, gs))
+    torch.cuda.synchronize()
+    for a, b in zip(*res):
+        assert torch.equal(a, b)

@@ -294,3 +294,29 @@ def test_fused_adamw_matches_torch_over_steps_and_under_graph_replay(decoupled, 
     step = GraphedStep(m3, crit, opt3, *data[0], warmup=1)       # the warm-up step is data[0]'s update
     step(*data[1])
     assert_close("adam under graph replay", m3.engine().pack.flat, want, 1e-6)
+
+
+def test_deferred_folds_leave_every_gradient_bit_identical(monkeypatch):
+    """The engine queues the small folds of a backward pass (ops.FoldQueue) and runs them in one launch: all parameter
+    gradients equal those of the fold-at-once form bit for bit."""
+    from oracle import vit_ref
+    from vit_torch_amd import CrossEntropyLoss, VisionTransformer
+    cfg = dict(img_size=32, patch_size=8, in_chans=3, embed_dim=64, depth=3, num_heads=2)
+    g = torch.Generator("cpu").manual_seed(3)
+    x = torch.randn(6, 3, 32, 32, generator=g).cuda()
+    y = torch.randint(0, 10, (6,), generator=g).cuda()
+    ref = vit_ref.VisionTransformer(**cfg, apply_head=True)
+    ref.head = vit_ref.get_classifier_head(64, 10)
+    vit_ref.seeded_init_(ref, 1)
+    grads = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("VITMI_DEFER_FOLDS", flag)
+        m = VisionTransformer(**cfg, apply_head=True, compute_dtype="bf16")
+        m.head = vit_ref.get_classifier_head(64, 10)
+        m.load_state_dict(ref.state_dict())
+        m = m.cuda()
+        CrossEntropyLoss()(m(x), y).backward()
+        assert (m.engine().folds is None) == (flag == "0")
+        grads.append({n: p.grad.clone() for n, p in m.named_parameters()})
+    for n in grads[0]:
+        assert torch.equal(grads[0][n], grads[1][n]), n

@@ -51,6 +51,20 @@ class GemmDesc(C.Structure):
         self.struct_size = C.sizeof(GemmDesc)      # the library rejects any other layout
 
 
+class FoldDesc(C.Structure):
+    """vitmi_fold_desc: one deferred fold of fp32 partial column sums (include/vitmi.h)."""
+    _fields_ = [
+        ("struct_size", c_i64),
+        ("part", c_vp), ("S", c_i32), ("nseg", c_i32),
+        ("N", c_i64), ("ld", c_i64),
+        ("out", c_vp * 3),
+    ]
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.struct_size = C.sizeof(FoldDesc)
+
+
 # name -> (restype, argtypes); every symbol declared in include/vitmi.h
 SIGNATURES = {
     "vitmi_version": (C.c_int, []),
@@ -66,6 +80,10 @@ SIGNATURES = {
     "vitmi_layernorm_bwd": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, C.c_int, c_i64, c_vp, c_vp, c_vp,
                                       c_vp, c_vp, C.c_int, c_i64, c_vp, C.c_int, c_i64, c_vp, c_vp, c_vp, c_vp,
                                       c_vp, c_i64, c_i64, c_i64, c_vp, c_sz, c_vp]),
+    "vitmi_layernorm_bwd_deferred": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, C.c_int, c_i64, c_vp, c_vp, c_vp,
+                                               c_vp, c_vp, C.c_int, c_i64, c_vp, C.c_int, c_i64, c_vp, c_vp, c_vp, c_vp,
+                                               c_vp, c_i64, c_i64, c_i64, c_vp, c_sz, C.POINTER(FoldDesc), c_vp]),
+    "vitmi_fold_many": (C.c_int, [C.POINTER(FoldDesc), C.c_int, c_vp]),
     "vitmi_attn_fwd": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_i64, c_f32, c_vp]),
     "vitmi_attn_bwd_workspace": (c_sz, [c_i64, c_i64, c_i64]),
     "vitmi_attn_bwd_dbias_rows": (c_i64, [c_i64, c_i64]),

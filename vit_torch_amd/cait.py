@@ -15,6 +15,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -175,6 +177,8 @@ class CaitEngine:
         self.pack = ParamPack(list(model.named_parameters()), dev, shadow=self.T == torch.bfloat16)
         self.saved = None
         self.reducer = None
+        # small folds of a backward pass in one launch per flush (ops.FoldQueue; VITMI_DEFER_FOLDS=0: at once)
+        self.folds = ops.FoldQueue() if os.environ.get("VITMI_DEFER_FOLDS", "1") != "0" else None
         self.profile = None
         self.gemm_impl = GEMM_AUTO
 
@@ -192,6 +196,8 @@ class CaitEngine:
     def _ready(self, *objs):
         if self.reducer is None:
             return
+        if self.folds is not None:
+            self.folds.flush()
         ps = []
         for o in objs:
             ps.extend(o.parameters() if isinstance(o, nn.Module) else [o])
@@ -336,6 +342,8 @@ class CaitEngine:
         try:
             self._backward(dout)
         except BaseException:
+            if self.folds is not None:
+                self.folds.clear()
             if self.reducer is not None:
                 self.reducer.abort()
             raise
@@ -384,7 +392,7 @@ class CaitEngine:
                           pk.g(m.norm.weight), pk.g(m.norm.bias),
                           gsum=pk.g(last.mlp.fc2.bias) if last is not None else None,
                           gb_scale=pk.f32(last.gamma_2) if last is not None else None,
-                          M=B, D=D, dy_stride=D, x_stride=D, g_stride=ldu, gb_stride=D)
+                          M=B, D=D, dy_stride=D, x_stride=D, g_stride=ldu, gb_stride=D, fold=self.folds)
         self._ready(m.norm, *([m.head] if self.head else []))
         for bi in range(len(cab) - 1, -1, -1):
             blk = cab[bi]
@@ -401,7 +409,7 @@ class CaitEngine:
             ops.colsum(dHc, pk.g(mlp.fc1.bias))
             ops.layernorm_bwd(dln2c, C1, mean2c, rstd2c, pk.f32(blk.norm2.weight), Gc, Gc, GCb,
                               pk.g(blk.norm2.weight), pk.g(blk.norm2.bias), gsum=pk.g(a.proj.bias),
-                              gb_scale=pk.f32(blk.gamma_1), M=B, D=D, g_stride=ldu, gb_stride=D)
+                              gb_scale=pk.f32(blk.gamma_1), M=B, D=D, g_stride=ldu, gb_stride=D, fold=self.folds)
             ops.colsum_mul(Gc, g1, pk.g(blk.gamma_1), M=B, N=D, ldx=ldu, ldy=D)
             doc = new(B, D, T)
             self._gemm(GCb, self._w(a.proj.weight), doc, b_kmajor=False)
@@ -423,7 +431,7 @@ class CaitEngine:
                 ops.colsum(dq, pk.g(a.q.bias))
             # through LN(u): adds into Gu (row 0 also carries the residual path of the CLS stream)
             ops.layernorm_bwd(dlnu, u, meanu, rstdu, pk.f32(blk.norm1.weight), Gu, Gu, None,
-                              pk.g(blk.norm1.weight), pk.g(blk.norm1.bias), M=Mu, D=D)
+                              pk.g(blk.norm1.weight), pk.g(blk.norm1.bias), M=Mu, D=D, fold=self.folds)
             if bi > 0:      # operand copy of the CLS gradient for the previous CA layer's MLP branch
                 prev = cab[bi - 1]
                 ops.scale_cast(Gc, GCb, pk.f32(prev.gamma_2), M=B, N=D, ldx=ldu)
@@ -458,7 +466,7 @@ class CaitEngine:
             fold()
             ops.layernorm_bwd(dln2, X1, mean2, rstd2, pk.f32(blk.norm2.weight), G, G, Gb,
                               pk.g(blk.norm2.weight), pk.g(blk.norm2.bias), gsum=pk.g(a.proj.bias),
-                              gb_scale=pk.f32(blk.gamma_1), M=M, D=D)
+                              gb_scale=pk.f32(blk.gamma_1), M=M, D=D, fold=self.folds)
             ops.colsum_mul(G, f1, pk.g(blk.gamma_1), M=M, N=D)
             dO = new(M, D, T)
             self._gemm(Gb, self._w(a.proj.weight), dO, b_kmajor=False)
@@ -491,7 +499,7 @@ class CaitEngine:
             ops.layernorm_bwd(dln1, X, mean1, rstd1, pk.f32(blk.norm1.weight), G, G, Gb,
                               pk.g(blk.norm1.weight), pk.g(blk.norm1.bias),
                               gsum=pk.g(prev.mlp.fc2.bias) if prev is not None else None,
-                              gb_scale=pk.f32(prev.gamma_2) if prev is not None else None, M=M, D=D)
+                              gb_scale=pk.f32(prev.gamma_2) if prev is not None else None, M=M, D=D, fold=self.folds)
             self._ready(blk)
 
         # ---- embeddings (no CLS row in the trunk: pos_embed is [Np, D])
@@ -504,5 +512,7 @@ class CaitEngine:
         if conv.bias is not None:
             ops.colsum(dpos.view(Np, D), pk.g(conv.bias))
         self._ready(m.cls_token, m.pos_embed, m.patch_embed)
+        if self.folds is not None:
+            self.folds.flush()
         if self.reducer is not None:
             self.reducer.finish()

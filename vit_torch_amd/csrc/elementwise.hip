@@ -206,6 +206,31 @@ __global__ __launch_bounds__(1024) void reduce_rows_segs_kernel(const float* __r
   }
 }
 
+// Many folds in ONE launch (round 3).  A training step folds ~50 small partial buffers (LayerNorm dgamma | dbeta | bias
+// sums, the fc1 / qkv bias partials of the GEMM and attention epilogues): each is 0.2-3 MB and a launch of its own costs
+// 5 us of ramp for 0.5 us of traffic.  The engines queue the folds of a backward pass (or of a gradient-bucket section)
+// and run them together: block b finds its fold in a prefix table of block counts (kernel argument, <= FOLD_MAX entries);
+// every output is summed by fold_rows exactly as in the single launches, so results do not change by a bit.
+constexpr int FOLD_MAX = 32;
+struct FoldTable {
+  const float* part[FOLD_MAX];
+  float* out[FOLD_MAX][3];
+  int S[FOLD_MAX], N[FOLD_MAX], ld[FOLD_MAX], blk_end[FOLD_MAX];
+  int n;
+};
+__global__ __launch_bounds__(1024) void fold_many_kernel(FoldTable t) {
+  __shared__ float red[FOLD_GROUPS][FOLD_COLS];
+  const int b = blockIdx.x;
+  int i = 0;
+  while (i < t.n - 1 && b >= t.blk_end[i]) ++i;                  // workgroup-uniform
+  const int lb = b - (i ? t.blk_end[i - 1] : 0);
+  const int N = t.N[i], cb = (N + FOLD_COLS - 1) / FOLD_COLS;
+  const int seg = lb / cb;
+  const int64_t c = (int64_t)(lb % cb) * FOLD_COLS + threadIdx.x % FOLD_COLS;
+  const float tot = fold_rows(t.part[i], t.S[i], t.ld[i], (int64_t)seg * N + c, c < N, red);
+  if (threadIdx.x < FOLD_COLS && c < N) t.out[i][seg][c] = tot;
+}
+
 inline int colsum_splits(int64_t M) {
   int64_t s = (M + 3) / 4;
   return (int)(s < 512 ? s : 512);
@@ -353,6 +378,31 @@ int vitmi_reduce_rows_segs(const float* part, int S, int64_t ld, float* const ou
   for (int i = 0; i < 4; ++i) { sg.out[i] = out[i]; e += width[i]; sg.end[i] = e; }
   hipLaunchKernelGGL(reduce_rows_segs_kernel, dim3((unsigned)((e + FOLD_COLS - 1) / FOLD_COLS)), dim3(1024), 0, stream, part, S, ld, sg);
   return vitmi_check_launch("reduce_rows_segs_kernel");
+}
+
+extern "C" int vitmi_fold_many(const vitmi_fold_desc* descs, int n, void* stream_) {
+  VITMI_REQUIRE(descs && n > 0, VITMI_E_BADARG, "fold_many: null descriptors or n <= 0");
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  for (int i0 = 0; i0 < n; i0 += FOLD_MAX) {
+    FoldTable t;
+    t.n = n - i0 < FOLD_MAX ? n - i0 : FOLD_MAX;
+    int blocks = 0;
+    for (int i = 0; i < FOLD_MAX; ++i) {
+      const vitmi_fold_desc& d = descs[i0 + (i < t.n ? i : 0)];    // unused entries repeat the first (never selected)
+      if (i < t.n) {
+        VITMI_REQUIRE(d.struct_size == (int64_t)sizeof(vitmi_fold_desc), VITMI_E_BADARG, "fold_many: descriptor size %lld, this library expects %zu", (long long)d.struct_size, sizeof(vitmi_fold_desc));
+        VITMI_REQUIRE(d.part && d.S > 0 && d.nseg >= 1 && d.nseg <= 3 && d.N > 0 && d.N < (1ll << 30) && d.ld >= d.nseg * d.N && d.ld < (1ll << 31),
+                      VITMI_E_SHAPE, "fold_many: descriptor %d: S %d, nseg %d, N %lld, ld %lld", i0 + i, d.S, d.nseg, (long long)d.N, (long long)d.ld);
+        for (int k = 0; k < d.nseg; ++k) VITMI_REQUIRE(d.out[k], VITMI_E_BADARG, "fold_many: descriptor %d: null output %d", i0 + i, k);
+        blocks += d.nseg * (int)((d.N + FOLD_COLS - 1) / FOLD_COLS);
+      }
+      t.part[i] = d.part; t.S[i] = d.S; t.N[i] = (int)d.N; t.ld[i] = (int)d.ld; t.blk_end[i] = blocks;
+      for (int k = 0; k < 3; ++k) t.out[i][k] = d.out[k < d.nseg ? k : 0];
+    }
+    hipLaunchKernelGGL(fold_many_kernel, dim3((unsigned)blocks), dim3(1024), 0, stream, t);
+    if (int rc = vitmi_check_launch("fold_many_kernel")) return rc;
+  }
+  return 0;
 }
 
 int vitmi_reduce_rows(const float* part, int S, int64_t N, int64_t ld, float* out, hipStream_t stream) {

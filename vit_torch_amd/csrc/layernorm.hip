@@ -505,6 +505,29 @@ extern "C" int vitmi_layernorm_bwd(const void* dy, int dy_dtype, int64_t dy_stri
                                    float* gsum, const float* gb_scale, const float* gb_rowscale,
                                    int64_t rows_per_group, int64_t M, int64_t D,
                                    void* workspace, size_t workspace_bytes, void* stream_) {
+  vitmi_fold_desc fold;
+  int rc = vitmi_layernorm_bwd_deferred(dy, dy_dtype, dy_stride, x, x_dtype, x_stride, mean, rstd, gamma, g_in, g_out, g_dtype,
+                                        g_stride, gb_out, gb_dtype, gb_stride, dgamma, dbeta, gsum, gb_scale, gb_rowscale,
+                                        rows_per_group, M, D, workspace, workspace_bytes, &fold, stream_);
+  if (rc) return rc;
+  return vitmi_fold_many(&fold, 1, stream_);
+}
+
+static void ln_fold_desc(vitmi_fold_desc* f, const float* part, int S, int64_t D, float* dgamma, float* dbeta, float* gsum) {
+  f->struct_size = (int64_t)sizeof(vitmi_fold_desc);
+  f->part = part; f->S = S; f->nseg = gsum ? 3 : 2; f->N = D; f->ld = 3 * D;
+  f->out[0] = dgamma; f->out[1] = dbeta; f->out[2] = gsum;
+}
+
+extern "C" int vitmi_layernorm_bwd_deferred(const void* dy, int dy_dtype, int64_t dy_stride, const void* x,
+                                            int x_dtype, int64_t x_stride, const float* mean,
+                                            const float* rstd, const float* gamma, const void* g_in,
+                                            void* g_out, int g_dtype, int64_t g_stride, void* gb_out,
+                                            int gb_dtype, int64_t gb_stride, float* dgamma, float* dbeta,
+                                            float* gsum, const float* gb_scale, const float* gb_rowscale,
+                                            int64_t rows_per_group, int64_t M, int64_t D,
+                                            void* workspace, size_t workspace_bytes, vitmi_fold_desc* fold, void* stream_) {
+  VITMI_REQUIRE(fold, VITMI_E_BADARG, "layernorm_bwd_deferred: null fold descriptor");
   int rc = check_ln_common(x, x_dtype, x_stride, M, D, "layernorm_bwd");
   if (rc) return rc;
   VITMI_REQUIRE(dy && mean && rstd && gamma && g_out && dgamma && dbeta, VITMI_E_BADARG, "layernorm_bwd: null argument");
@@ -552,7 +575,8 @@ extern "C" int vitmi_layernorm_bwd(const void* dy, int dy_dtype, int64_t dy_stri
 #undef LN_BWD8_T
     rc = vitmi_check_launch("ln_bwd8_kernel");
     if (rc) return rc;
-    return vitmi_reduce_rows3(part, nb8, D, 3 * D, dgamma, dbeta, gsum, stream);
+    ln_fold_desc(fold, part, nb8, D, dgamma, dbeta, gsum);
+    return 0;
   }
   const int nblk = ln_bwd_blocks(M, D);
   const size_t lds = 4 * (size_t)D * sizeof(float);
@@ -584,5 +608,6 @@ extern "C" int vitmi_layernorm_bwd(const void* dy, int dy_dtype, int64_t dy_stri
 #undef LN_BWD_NV
   rc = vitmi_check_launch("ln_bwd_kernel");
   if (rc) return rc;
-  return vitmi_reduce_rows3(part, nblk, D, 3 * D, dgamma, dbeta, gsum, stream);
+  ln_fold_desc(fold, part, nblk, D, dgamma, dbeta, gsum);
+  return 0;
 }

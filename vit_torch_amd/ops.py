@@ -12,7 +12,7 @@ import torch
 
 from . import _lib
 from ._lib import (BF16, EPI_BIAS_GELU, EPI_DGELU, EPI_PATCH_POS, EPI_RESIDUAL, EPI_STORE, F32,
-                   GEMM_AUTO, GEMM_FAST, GEMM_GENERIC, GemmDesc, check, load)
+                   GEMM_AUTO, GEMM_FAST, GEMM_GENERIC, FoldDesc, GemmDesc, check, load)
 
 _WS: dict = {}
 
@@ -207,16 +207,55 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps, *, M=None, D=None, x_strid
     return y
 
 
+class FoldQueue:
+    """Deferred folds of fp32 partial column sums (vitmi_fold_many): the engines queue the ~50 small folds of a backward
+    pass (LayerNorm dgamma | dbeta | bias sums, the bias partials of the GEMM / attention epilogues) and run them in one
+    launch per flush — at the end of backward, or before a gradient-bucket section is handed to the reducer.  The queue
+    keeps the partial buffers alive until then.  Results are bit-identical to the single folds."""
+
+    def __init__(self):
+        self._descs, self._keep = [], []
+
+    def add(self, part, S, N, ld, outs, keep=()):
+        d = FoldDesc()
+        d.part, d.S, d.nseg, d.N, d.ld = part.data_ptr(), int(S), len(outs), int(N), int(ld)
+        for k, o in enumerate(outs):
+            assert o.dtype == torch.float32 and o.numel() >= N
+            d.out[k] = o.data_ptr()
+        self._descs.append(d)
+        self._keep.append((part, outs, keep))
+
+    def add_desc(self, d, keep):
+        self._descs.append(d)
+        self._keep.append(keep)
+
+    def __len__(self):
+        return len(self._descs)
+
+    def flush(self):
+        if not self._descs:
+            return
+        arr = (FoldDesc * len(self._descs))(*self._descs)
+        try:
+            check(load().vitmi_fold_many(arr, len(self._descs), _stream()), "vitmi_fold_many")
+        finally:
+            self._descs, self._keep = [], []
+
+    def clear(self):
+        self._descs, self._keep = [], []
+
+
 def layernorm_bwd(dy, x, mean, rstd, gamma, g_in, g_out, gb_out, dgamma, dbeta, *, gsum=None,
                   gb_scale=None, gb_rowscale=None, rows_per_group=0, M=None, D=None, dy_stride=None,
-                  x_stride=None, g_stride=None, gb_stride=None):
+                  x_stride=None, g_stride=None, gb_stride=None, fold=None):
+    """fold (a FoldQueue): leave the fold of the dgamma | dbeta | gsum partials to the queue's next flush; the partial
+    rows then live in a buffer of their own (kept by the queue) instead of the shared workspace."""
     _need_cuda(dy, x, g_out)
     D = D or x.shape[-1]
     M = M or dy.numel() // D
     lib = load()
     nbytes = lib.vitmi_layernorm_bwd_workspace(M, D)
-    ws = workspace(nbytes, dy.device)
-    check(lib.vitmi_layernorm_bwd(
+    args = (
         dy.data_ptr(), dtype_code(dy), dy_stride if dy_stride is not None else D,
         x.data_ptr(), dtype_code(x), x_stride if x_stride is not None else D,
         mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
@@ -224,8 +263,16 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, g_in, g_out, gb_out, dgamma, dbeta, 
         _ptr(gb_out), dtype_code(gb_out) if gb_out is not None else dtype_code(dy),
         gb_stride if gb_stride is not None else D,
         dgamma.data_ptr(), dbeta.data_ptr(), _ptr(gsum), _ptr(gb_scale), _ptr(gb_rowscale), rows_per_group,
-        M, D, ws.data_ptr(), ws.numel(), _stream()),
-        "vitmi_layernorm_bwd")
+        M, D)
+    if fold is None:
+        ws = workspace(nbytes, dy.device)
+        check(lib.vitmi_layernorm_bwd(*args, ws.data_ptr(), ws.numel(), _stream()), "vitmi_layernorm_bwd")
+        return
+    part = torch.empty(int(nbytes), dtype=torch.uint8, device=dy.device)
+    d = FoldDesc()
+    check(lib.vitmi_layernorm_bwd_deferred(*args, part.data_ptr(), part.numel(), C.byref(d), _stream()),
+          "vitmi_layernorm_bwd_deferred")
+    fold.add_desc(d, (part, dgamma, dbeta, gsum))
 
 
 def attn_fwd(qkv, out, lse, B, N, H, hd, scale):
@@ -293,12 +340,19 @@ def pos_resample(src, table, out=None):
     return out
 
 
-def colsum(x, out, *, M=None, N=None, ld=None):
+FOLD_DIRECT_ROWS = 2048      # vitmi_colsum folds an fp32 matrix of at most this many rows in one reduce_rows launch
+
+
+def colsum(x, out, *, M=None, N=None, ld=None, fold=None):
+    """fold (a FoldQueue): a short fp32 matrix (a partial buffer) is queued instead of folded now — the same sum."""
     _need_cuda(x, out)
     N = N or x.shape[-1]
     M = M or x.numel() // N
     ld = ld or N
     assert out.dtype == torch.float32 and out.numel() >= N
+    if fold is not None and x.dtype == torch.float32 and M <= FOLD_DIRECT_ROWS:
+        fold.add(x, M, N, ld, [out])
+        return out
     lib = load()
     ws = workspace(lib.vitmi_colsum_workspace(M, N), x.device)
     check(lib.vitmi_colsum(x.data_ptr(), dtype_code(x), M, N, ld, out.data_ptr(), ws.data_ptr(),

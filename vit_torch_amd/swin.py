@@ -22,6 +22,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -221,6 +223,8 @@ class SwinEngine:
         self.pack = ParamPack(list(model.named_parameters()), dev, shadow=self.T == torch.bfloat16)
         self.saved = None
         self.reducer = None
+        # small folds of a backward pass in one launch per flush (ops.FoldQueue; VITMI_DEFER_FOLDS=0: at once)
+        self.folds = ops.FoldQueue() if os.environ.get("VITMI_DEFER_FOLDS", "1") != "0" else None
         self.profile = None
         # bf16 patch-embed weight at the padded contraction width (see forward); allocated here so
         # that it never lands in a graph's private pool
@@ -244,6 +248,8 @@ class SwinEngine:
     def _ready(self, *objs):
         if self.reducer is None:
             return
+        if self.folds is not None:
+            self.folds.flush()
         ps = []
         for o in objs:
             ps.extend(o.parameters() if isinstance(o, nn.Module) else [o])
@@ -400,6 +406,8 @@ class SwinEngine:
         try:
             self._backward(dout)
         except BaseException:
+            if self.folds is not None:
+                self.folds.clear()
             if self.reducer is not None:
                 self.reducer.abort()
             raise
@@ -443,7 +451,7 @@ class SwinEngine:
         # Gb = (dropped-path-scaled) gradient of the last block's MLP branch output
         ops.layernorm_bwd(dxn, s["Xf"], s["meanf"], s["rstdf"], pk.f32(m.norm.weight), None, G, Gb,
                           pk.g(m.norm.weight), pk.g(m.norm.bias), gsum=pk.g(last_blk.mlp.fc2.bias),
-                          gb_rowscale=s["stages"][-1][0][-1][-1], rows_per_group=L, M=M, D=C)
+                          gb_rowscale=s["stages"][-1][0][-1][-1], rows_per_group=L, M=M, D=C, fold=self.folds)
         self._ready(m.norm, *([m.head] if self.head else []))
 
         layers = list(m.layers)
@@ -464,7 +472,7 @@ class SwinEngine:
                 self._gemm(Gb, lnm, pk.g(ds.reduction.weight), a_kmajor=False, b_kmajor=False)
                 Gm = new(M2, 4 * C, R)
                 ops.layernorm_bwd(dlnm, Xm, meanm, rstdm, pk.f32(ds.norm.weight), None, Gm, None,
-                                  pk.g(ds.norm.weight), pk.g(ds.norm.bias), M=M2, D=4 * C)
+                                  pk.g(ds.norm.weight), pk.g(ds.norm.bias), M=M2, D=4 * C, fold=self.folds)
                 G, Gb = new(M, C, R), new(M, C, T)
                 ops.patch_merge(Gm, G, B, Hh, Ww, C, inverse=True)
                 ops.scale_cast(G, Gb, None, M=M, N=C, rowscale=blocks_saved[-1][-1], rows_per_group=L)
@@ -489,7 +497,7 @@ class SwinEngine:
                 fold()
                 ops.layernorm_bwd(dln2, X1, mean2, rstd2, pk.f32(blk.norm2.weight), G, G, Gb,
                                   pk.g(blk.norm2.weight), pk.g(blk.norm2.bias), gsum=pk.g(a.proj.bias),
-                                  gb_rowscale=rs1, rows_per_group=L, M=M, D=C)
+                                  gb_rowscale=rs1, rows_per_group=L, M=M, D=C, fold=self.folds)
                 dO = new(M, C, T)
                 self._gemm(Gb, self._w(a.proj.weight), dO, b_kmajor=False)
                 self._gemm(Gb, O, pk.g(a.proj.weight), a_kmajor=False, b_kmajor=False)
@@ -509,7 +517,7 @@ class SwinEngine:
                 ops.layernorm_bwd(dln1, X, mean1, rstd1, pk.f32(blk.norm1.weight), G, G, Gb,
                                   pk.g(blk.norm1.weight), pk.g(blk.norm1.bias),
                                   gsum=pk.g(prev_bias) if prev_bias is not None else None,
-                                  gb_rowscale=rs_prev, rows_per_group=L, M=M, D=C)
+                                  gb_rowscale=rs_prev, rows_per_group=L, M=M, D=C, fold=self.folds)
                 self._ready(blk)
 
         # patch embedding (+ its LayerNorm)
@@ -523,7 +531,7 @@ class SwinEngine:
             dY, dYb = new(M, C, R), new(M, C, T)
             gdt = G if R == f32 else G     # dy of this LN is the residual-stream gradient itself
             ops.layernorm_bwd(gdt, Y, meanp, rstdp, pk.f32(pe.norm.weight), None, dY, dYb,
-                              pk.g(pe.norm.weight), pk.g(pe.norm.bias), gsum=pk.g(pe.proj.bias), M=M, D=C)
+                              pk.g(pe.norm.weight), pk.g(pe.norm.bias), gsum=pk.g(pe.proj.bias), M=M, D=C, fold=self.folds)
             Gb = dYb
         else:
             ops.colsum(Gb, pk.g(pe.proj.bias))
@@ -534,5 +542,7 @@ class SwinEngine:
         else:
             self._gemm(Gb, s["patches"], pk.g(pe.proj.weight).view(C, Kp), a_kmajor=False, b_kmajor=False)
         self._ready(m.patch_embed)
+        if self.folds is not None:
+            self.folds.flush()
         if self.reducer is not None:
             self.reducer.finish()

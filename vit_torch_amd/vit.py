@@ -223,7 +223,7 @@ def dgelu_gemm_with_bias_grad(eng, Gb, W2, dH, pre, bias_grad):
     if fused:
         part = torch.empty(((M + 127) // 128, Dh), dtype=torch.float32, device=dH.device)
         eng._gemm(Gb, W2, dH, b_kmajor=False, epilogue=EPI_DGELU, aux=pre, colsum_part=part)
-        return lambda: ops.colsum(part, bias_grad)
+        return lambda: ops.colsum(part, bias_grad, fold=getattr(eng, "folds", None))
     eng._gemm(Gb, W2, dH, b_kmajor=False, epilogue=EPI_DGELU, aux=pre)
     return lambda: ops.colsum(dH, bias_grad)
 
@@ -259,6 +259,9 @@ class VitEngine:
         # 256x256-tile GEMM workgroup owns its CU's whole register file and 128 KiB of LDS, so
         # two GEMM kernels only take CUs from each other.  Removed.)
         self.fused_bias_grads = os.environ.get("VITMI_FUSED_BIAS_GRADS", "1") != "0"
+        # the ~50 small folds of a backward pass (LayerNorm dgamma | dbeta | bias sums, fc1 / qkv bias partials) run as
+        # ONE launch per flush instead of one each (ops.FoldQueue; VITMI_DEFER_FOLDS=0: fold at once, for A/B)
+        self.folds = ops.FoldQueue() if os.environ.get("VITMI_DEFER_FOLDS", "1") != "0" else None
 
     def is_current(self) -> bool:
         m = self.model
@@ -275,6 +278,8 @@ class VitEngine:
     def _ready(self, *mods_or_params):
         if self.reducer is None:
             return
+        if self.folds is not None:
+            self.folds.flush()              # the section's bias / LayerNorm gradients must be final before its bucket leaves
         ps = []
         for o in mods_or_params:
             ps.extend(o.parameters() if isinstance(o, nn.Module) else [o])
@@ -396,6 +401,8 @@ class VitEngine:
         try:
             self._backward(dout)
         except BaseException:
+            if self.folds is not None:
+                self.folds.clear()
             if self.reducer is not None:
                 self.reducer.abort()
             raise
@@ -439,7 +446,7 @@ class VitEngine:
         last_fc2_bias = m.blocks[-1].mlp.fc2.bias
         ops.layernorm_bwd(dfeat, s["Xf"], s["meanf"], s["rstdf"], pk.f32(m.norm.weight), None, G, None,
                           pk.g(m.norm.weight), pk.g(m.norm.bias), gsum=pk.g(last_fc2_bias), M=B, D=D,
-                          dy_stride=D, x_stride=N * D, g_stride=N * D)
+                          dy_stride=D, x_stride=N * D, g_stride=N * D, fold=self.folds)
         self._ready(m.norm, *([m.head] if self.head else []))
         if T == R:
             Gb = G                      # GEMM operand and residual gradient share one buffer
@@ -470,12 +477,12 @@ class VitEngine:
                        **({"colsum_part": dH_part} if dH_part is not None else {}))
             self._gemm(Gb, hid, pk.g(mlp.fc2.weight), a_kmajor=False, b_kmajor=False)
             self._gemm(dH, ln2, pk.g(mlp.fc1.weight), a_kmajor=False, b_kmajor=False)
-            ops.colsum(dH_part if dH_part is not None else dH, pk.g(mlp.fc1.bias))
+            ops.colsum(dH_part if dH_part is not None else dH, pk.g(mlp.fc1.bias), fold=self.folds)
             dln2 = new(M, D, T)
             self._gemm(dH, self._w(mlp.fc1.weight), dln2, b_kmajor=False)
             ops.layernorm_bwd(dln2, X1, mean2, rstd2, pk.f32(blk.norm2.weight), G, G, gb_out,
                               pk.g(blk.norm2.weight), pk.g(blk.norm2.bias), gsum=pk.g(a.proj.bias),
-                              M=M, D=D)
+                              M=M, D=D, fold=self.folds)
             # attention branch
             dO = new(M, D, T)
             self._gemm(Gb, self._w(a.proj.weight), dO, b_kmajor=False)
@@ -489,14 +496,15 @@ class VitEngine:
             # LayerNorm backward below is what overwrites it)
             engine_wgrad_pair(self, Gb, O, pk.g(a.proj.weight), dqkv, ln1, pk.g(a.qkv.weight))
             if a.qkv.bias is not None:
-                ops.colsum(dqkv_part if dqkv_part is not None else dqkv, pk.g(a.qkv.bias))
+                ops.colsum(dqkv_part if dqkv_part is not None else dqkv, pk.g(a.qkv.bias), fold=self.folds)
             dln1 = new(M, D, T)
             self._gemm(dqkv, self._w(a.qkv.weight), dln1, b_kmajor=False)
             # the gradient this leaves in G flows into the previous block's fc2 output
             prev_fc2_bias = blocks_list[bi - 1].mlp.fc2.bias if bi > 0 else None
             ops.layernorm_bwd(dln1, X, mean1, rstd1, pk.f32(blk.norm1.weight), G, G, gb_out,
                               pk.g(blk.norm1.weight), pk.g(blk.norm1.bias),
-                              gsum=pk.g(prev_fc2_bias) if prev_fc2_bias is not None else None, M=M, D=D)
+                              gsum=pk.g(prev_fc2_bias) if prev_fc2_bias is not None else None, M=M, D=D,
+                              fold=self.folds)
             self._ready(blk)
 
         # ---- embeddings ----
@@ -513,5 +521,7 @@ class VitEngine:
         if conv.bias is not None:
             ops.colsum(dpos[D:].view(N - 1, D), pk.g(conv.bias))  # CLS rows carry no conv bias
         self._ready(m.cls_token, m.pos_embed, m.patch_embed)
+        if self.folds is not None:
+            self.folds.flush()
         if self.reducer is not None:
             self.reducer.finish()
