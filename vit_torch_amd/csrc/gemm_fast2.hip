@@ -17,6 +17,7 @@
 //   issue LDS-DMA of slab j+2 into the stage slab j-1 occupied
 //   12 fragment reads of slab j, 32 MFMAs
 // LDS images, swizzles, epilogue: as gemm_fast.hip (gemm_tile.h).
+#include <type_traits>
 #include "gemm_tile.h"
 
 namespace {
@@ -74,10 +75,12 @@ template <bool KM, int ROWS> struct Plan2 {
       step = 64 * ld;
     }
   }
+  // SGPR base + 32-bit lane offset, from inline asm (round 3, as in gemm_fast.hip): no 64-bit vector add per DMA, and the
+  // DMAs stay out of hipcc's vmcnt bookkeeping — every wait of the main loop is an explicit counted one
   __device__ __forceinline__ void issue(char* slab, int j, int wave) const {
 #pragma unroll
     for (int i = 0; i < NP; ++i)
-      glds16(base[i] + (int64_t)j * step + off[i], slab + (wave * NP + i) * 1024);
+      glds16_sbase(base[i] + (int64_t)j * step, off[i], slab + (wave * NP + i) * 1024);
   }
 };
 
@@ -185,19 +188,22 @@ __global__ __launch_bounds__(NT2, 2) void gemm_fast2_kernel(GemmArgs g, int tile
   for (int mi = 0; mi < 8; ++mi) fa[mi] = frag_off2<A_KM, 256>(wm * 8 + mi, lane);
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) fb[ni] = frag_off2<B_KM, 128>(wn * 4 + ni, lane) + A_SLAB;
-  auto issue = [&](int j) {
-    char* st = smem + (j % RING2) * STAGE2;
+  auto issue = [&](int j, int st_i) {
+    char* st = smem + st_i * STAGE2;
     pa.issue(st, j, wave);
     pb_.issue(st + A_SLAB, j, wave);
   };
-  issue(0);
-  if (ns > 1) issue(1);
+  issue(0, 0);
+  if (ns > 1) issue(1, 1);
   int stage = 0;
-#pragma unroll 1
-  for (int j = 0; j < ns; ++j) {
-    wait_vm6(j + 1 < ns);                          // my 6 LDS-DMA of slab j are done (slab j+1's may fly)
+  // STEADY (j + 2 < ns): slab j + 1 is always in flight behind slab j (vmcnt(6)) and slab j + 2 is always issued — as
+  // compile-time facts, so the loop carries no branch around the wait and the issue; the last two slabs take the general form
+  auto slab = [&](int j, auto steady_tag) {
+    constexpr bool STEADY = decltype(steady_tag)::value;
+    if constexpr (STEADY) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else wait_vm6(j + 1 < ns);                     // my 6 LDS-DMA of slab j are done (slab j+1's may fly)
     raw_barrier();                                 // slab j visible to all; slab j-1 no longer read
-    if (j + 2 < ns) issue(j + 2);                  // into the stage of slab j-1
+    if (STEADY || j + 2 < ns) issue(j + 2, stage == 0 ? RING2 - 1 : stage - 1);     // into the stage of slab j-1
     const char* As = smem + stage * STAGE2;
     Frag2<B_KM, 256> fbv[4];
     Frag2<A_KM, 512> fav[8];
@@ -221,7 +227,12 @@ __global__ __launch_bounds__(NT2, 2) void gemm_fast2_kernel(GemmArgs g, int tile
       for (int ni = 0; ni < 4; ++ni)
         acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[ni][mi], 0, 0, 0);
     stage = stage == RING2 - 1 ? 0 : stage + 1;
-  }
+  };
+  int j = 0;
+#pragma unroll 1
+  for (; j + 2 < ns; ++j) slab(j, std::true_type{});
+#pragma unroll 1
+  for (; j < ns; ++j) slab(j, std::false_type{});
   raw_barrier();                                   // every wave is done reading the ring
 
   // ---- epilogue: wave-private LDS transpose strips, full-line row accesses (gemm_tile.h)
