@@ -152,11 +152,24 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(SmallArgs a) {
     const int RSB = 64 * 2 + 16;                   // 64 k (zero beyond K) + pad: conflict-free row reads
     stage_rows(smem, RSB, B, a.ldb, 0, tiles_n * 16, N, K, 64, tid, 256);
     __syncthreads();
+    // the NEXT row tile's A fragments are loaded while this one's column tiles are contracted and stored (round 3: the
+    // load of a row tile used to sit at the top of its iteration, one exposed global round trip per 16 rows and wave;
+    // q k^T 73.7 -> 69.1 us, dO v^T 77.7 -> 70.3 us at CaiT-S24's 2048 problems, tools/cait_bgemm_bench.py)
+    bf16x8 afn[2];
+    {
+      const int row0 = min((w + 4 * part) * 16 + li, M - 1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) afn[ks] = ks < ksteps ? row_frag(A, a.lda, row0, ks * 32 + 8 * g, K) : zero8();
+    }
     for (int rt = w + 4 * part; rt < tiles_m; rt += 4 * parts) {
-      const int row = min(rt * 16 + li, M - 1);
       bf16x8 af[2];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) af[ks] = ks < ksteps ? row_frag(A, a.lda, row, ks * 32 + 8 * g, K) : zero8();
+      for (int ks = 0; ks < 2; ++ks) af[ks] = afn[ks];
+      {
+        const int rown = min(min(rt + 4 * parts, tiles_m - 1) * 16 + li, M - 1);       // unconditional (the last one re-reads)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) afn[ks] = ks < ksteps ? row_frag(A, a.lda, rown, ks * 32 + 8 * g, K) : zero8();
+      }
       for (int ct = 0; ct < tiles_n; ++ct) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -186,7 +199,8 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(SmallArgs a) {
 #pragma unroll
         for (int ct = 0; ct < SB_MAXN / 16; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
         // (all k-steps' fragments in one batch of loads was tried: 38 -> 144 VGPRs, three
-        // instead of eight waves per SIMD, 16.7 -> 28 us; occupancy hides this chain better)
+        // instead of eight waves per SIMD, 16.7 -> 28 us; occupancy hides this chain better.  Round 3: only the NEXT
+        // k-step's fragment in flight, +4 VGPRs: 73.5 / 76.6 -> 73.8 / 79.5 us at 2048 problems — no gain either)
         for (int ks = 0; ks < Kp / 32; ++ks) {
           const bf16x8 af = row_frag(A, a.lda, row, ks * 32 + 8 * g, K);
 #pragma unroll
