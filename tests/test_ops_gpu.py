@@ -1057,3 +1057,39 @@ def test_layernorm_bwd_deferred_fold_equals_the_immediate_one(ops, M, D, T, R):
     torch.cuda.synchronize()
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+# ----------------------------------------------------- skinny fp32 GEMMs ---
+@pytest.mark.parametrize("akm,bkm,M,N,K", [(True, True, 256, 10, 768), (True, True, 37, 16, 100), (True, True, 5, 1, 64),
+                                           (True, False, 256, 768, 10), (True, False, 33, 70, 32),
+                                           (False, False, 10, 768, 256), (False, False, 32, 45, 1000)])
+def test_gemm_skinny_fp32_forms(ops, akm, bkm, M, N, K):
+    """The classifier head's fp32 products take the plain-FMA kernels (gemm_skinny_kernel) by default: against fp32 torch
+    math and against the 64x64-tile kernel (impl = GENERIC), with bias / alpha / accumulate through the same epilogue."""
+    from vit_torch_amd._lib import GEMM_GENERIC
+    a, b, bias = gen((M, K), 1), gen((N, K), 2), gen((N,), 3)
+    A = dev(a if akm else a.t().contiguous())
+    B = dev(b if bkm else b.t().contiguous())
+    C, Cg = torch.empty((M, N), device="cuda"), torch.empty((M, N), device="cuda")
+    ops.gemm(A, B, C, a_kmajor=akm, b_kmajor=bkm, bias=dev(bias), alpha=0.5)
+    ops.gemm(A, B, Cg, a_kmajor=akm, b_kmajor=bkm, bias=dev(bias), alpha=0.5, impl=GEMM_GENERIC)
+    assert_close("skinny", C, 0.5 * (a @ b.t()) + bias, 2e-5)
+    assert_close("skinny vs generic", C, Cg.cpu(), 2e-5)
+    ops.gemm(A, B, C, a_kmajor=akm, b_kmajor=bkm, accumulate=True)
+    assert_close("skinny accumulate", C, 1.5 * (a @ b.t()) + bias, 2e-5)
+
+
+def test_gemm_skinny_gelu_pair(ops):
+    """Head with a hidden GELU layer: EPI_BIAS_GELU (second output = pre-activation) and EPI_DGELU through the skinny forms."""
+    from vit_torch_amd._lib import EPI_BIAS_GELU, EPI_DGELU
+    M, N, K = 64, 12, 256
+    a, w, bias = gen((M, K), 1), gen((N, K), 2) * 0.1, gen((N,), 3)
+    pre = a @ w.t() + bias
+    C, P = torch.empty((M, N), device="cuda"), torch.empty((M, N), device="cuda")
+    ops.gemm(dev(a), dev(w), C, epilogue=EPI_BIAS_GELU, bias=dev(bias), C2=P)
+    assert_close("gelu", C, F.gelu(pre), 2e-5)
+    assert_close("pre", P, pre, 2e-5)
+    d, w2 = gen((M, 7), 4), gen((7, N), 5)          # dx = (d @ w2) * gelu'(pre): K = 7 -> FORM 1
+    dx = torch.empty((M, N), device="cuda")
+    ops.gemm(dev(d), dev(w2), dx, b_kmajor=False, epilogue=EPI_DGELU, aux=P)
+    assert_close("dgelu", dx, (d @ w2) * gelu_grad(pre), 2e-5)

@@ -144,7 +144,101 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs g) {
   }
 }
 
+// ---- skinny fp32 products (the classifier head: 256 x 10 x 768 and its two gradients).  The 64x64-tile kernel above runs
+// them on 4-12 workgroups as a staged loop of K / 32 dependent global -> LDS -> MFMA steps: 39 us per launch for 4 MFLOP,
+// three launches per step.  Plain FMAs with every lane on its own part of the contraction take a few us (round 3).
+//   FORM 0  C[m][n] = sum_k A[m][k] B[n][k],  N <= 16   (logits = feat W^T): one workgroup per row m, a quarter of k per wave,
+//           lanes stride over k, the N partial sums folded across the wave in a fixed butterfly order
+//   FORM 1  C[m][n] = sum_k A[m][k] B[k][n],  K <= 32   (d feat = d logits W): one thread per output
+//   FORM 2  C[m][n] = sum_k A[k][m] B[k][n],  M <= 32   (d W = d logits^T feat): 32 outputs x 8 k-slices per workgroup
+// Every sum has a fixed order (deterministic); the epilogue is the generic kernel's (epi_store1_rt).
+constexpr int SKINNY_MAXN = 16;
+template <int FORM>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
+  const float* __restrict__ A = reinterpret_cast<const float*>(g.A);
+  const float* __restrict__ B = reinterpret_cast<const float*>(g.B);
+  if constexpr (FORM == 0) {
+    // a workgroup per row m: its four waves take a quarter of the contraction each (lanes stride over k), fold their N
+    // partial sums across the wave, and wave 0 adds the four quarters in a fixed order
+    __shared__ float quarter[4][SKINNY_MAXN];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t m = blockIdx.x;
+    float acc[SKINNY_MAXN];
+#pragma unroll
+    for (int n = 0; n < SKINNY_MAXN; ++n) acc[n] = 0.f;
+    const int N = (int)g.N;
+    // rows of B beyond N re-read the last one, unconditionally: a branch around a load would give each its own round trip
+    const float* Bn[SKINNY_MAXN];
+#pragma unroll
+    for (int n = 0; n < SKINNY_MAXN; ++n) Bn[n] = B + (int64_t)(n < N ? n : N - 1) * g.ldb;
+    const float* Am = A + m * g.lda;
+    const int64_t per = ((g.K + 3) / 4 + 63) / 64 * 64;                      // a quarter, in whole 64-lane strides
+    const int64_t k0 = w * per, k1 = k0 + per < g.K ? k0 + per : g.K;
+#pragma unroll 4
+    for (int64_t kb = k0; kb < k1; kb += 64) {
+      const int64_t k = kb + lane, kc = k < k1 ? k : k1 - 1;               // clamped loads, zeroed factor at the ragged end
+      const float a = k < k1 ? Am[kc] : 0.f;
+#pragma unroll
+      for (int n = 0; n < SKINNY_MAXN; ++n) acc[n] = fmaf(a, Bn[n][kc], acc[n]);
+    }
+#pragma unroll
+    for (int n = 0; n < SKINNY_MAXN; ++n) {
+      float v = acc[n];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == n) quarter[w][n] = v;
+    }
+    __syncthreads();
+    if (w == 0 && lane < N) epi_store1_rt(g.e, m, lane, (quarter[0][lane] + quarter[1][lane]) + (quarter[2][lane] + quarter[3][lane]));
+  } else if constexpr (FORM == 1) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= g.M * g.N) return;
+    const int64_t m = i / g.N, n = i % g.N;
+    float acc = 0.f;
+    for (int64_t k = 0; k < g.K; ++k) acc = fmaf(A[m * g.lda + k], B[k * g.ldb + n], acc);
+    epi_store1_rt(g.e, m, n, acc);
+  } else {
+    // a workgroup = 32 consecutive outputs (n fastest) x 8 slices of the contraction; the slices are added in a fixed order
+    __shared__ float part[8][32];
+    const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int64_t i = (int64_t)blockIdx.x * 32 + o, tot = g.M * g.N;
+    const int64_t ic = i < tot ? i : tot - 1;        // clamped: every thread loads, only valid ones store
+    const int64_t m = ic / g.N, n = ic % g.N;
+    const int64_t per = (g.K + 7) / 8, k0 = sl * per, k1 = k0 + per < g.K ? k0 + per : g.K;
+    float acc = 0.f;
+#pragma unroll 4
+    for (int64_t k = k0; k < k1; ++k) acc = fmaf(A[k * g.lda + m], B[k * g.ldb + n], acc);
+    part[sl][o] = acc;
+    __syncthreads();
+    if (sl == 0 && i < tot) {
+      float v = part[0][o];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) v += part[q][o];
+      epi_store1_rt(g.e, m, n, v);
+    }
+  }
+}
+
 }  // namespace
+
+static int g_skinny = 1;             // diagnostic / test hook: 0 = the head's products stay on the 64x64-tile kernel
+extern "C" void vitmi_debug_gemm_skinny(int on) { g_skinny = on != 0; }
+// which fp32 problems take the skinny kernel: -1 = none
+static int gemm_skinny_form(const GemmArgs& g, int in_bf16) {
+  if (!g_skinny || in_bf16 || g.batch != 1 || g.M * g.N > (1ll << 24)) return -1;
+  if (g.a_km && g.b_km) return (g.N <= SKINNY_MAXN && g.K >= 64) ? 0 : -1;
+  if (g.a_km && !g.b_km) return g.K <= 32 ? 1 : -1;
+  if (!g.a_km && !g.b_km) return (g.M <= 32 && g.K <= 8192) ? 2 : -1;
+  return -1;
+}
+static int gemm_skinny_launch(const GemmArgs& g, int form, hipStream_t stream) {
+  if (form == 0) hipLaunchKernelGGL(gemm_skinny_kernel<0>, dim3((unsigned)g.M), dim3(256), 0, stream, g);
+  else {
+    if (form == 1) hipLaunchKernelGGL(gemm_skinny_kernel<1>, dim3((unsigned)((g.M * g.N + 255) / 256)), dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL(gemm_skinny_kernel<2>, dim3((unsigned)((g.M * g.N + 31) / 32)), dim3(256), 0, stream, g);
+  }
+  return vitmi_check_launch("gemm_skinny_kernel");
+}
 
 // Cache policy of the tile kernels' output stores (storev_pol): -1 = automatic, else forced (diagnostic hook).
 // Automatic: `nt` for the wide activation outputs that are written once and read by a LATER kernel
@@ -326,6 +420,10 @@ extern "C" int vitmi_gemm(const vitmi_gemm_desc* d, void* stream_) {
   if (d->impl != VITMI_GEMM_GENERIC || g_small_override == 1) {     // batched form: one workgroup per small problem
     const int form = g_small_override == 0 ? -1 : gemm_small_form(g, in_bf16 ? 1 : 0);
     if (form >= 0 && small_lds_ok(g, form)) return gemm_small_launch(g, form, stream);
+  }
+  if (d->impl != VITMI_GEMM_GENERIC) {                              // the classifier head's fp32 products
+    const int sform = gemm_skinny_form(g, in_bf16 ? 1 : 0);
+    if (sform >= 0) return gemm_skinny_launch(g, sform, stream);
   }
   dim3 grid((unsigned)((g.N + GBN - 1) / GBN), (unsigned)((g.M + GBM - 1) / GBM), (unsigned)g.batch);
   VITMI_REQUIRE(grid.y <= 65535u, VITMI_E_SHAPE, "gemm: M too large for the generic kernel grid");
