@@ -93,3 +93,34 @@ def test_graph_static_inputs_written_in_place(lib):
         lb = b(b.x, b.y).item()                    # written in place by the "loader"
         assert la == lb
     assert torch.equal(ma.engine().pack.flat, mb.engine().pack.flat)
+
+
+def test_graph_without_the_weight_cast_follows_weights_changed_between_replays(lib):
+    """With a fused optimizer over all parameters the fp32 -> bf16 weight cast stays out of the captured graph (the optimizer
+    kernel writes master and shadow together); GraphedStep checks the pack's version key eagerly before each replay, so
+    weights loaded between replays are still used.  A stock torch optimizer keeps the recorded cast."""
+    from vit_torch_amd.graph import GraphedStep
+    data = _batches(3)
+    m, crit, opt = _make()
+    step = GraphedStep(m, crit, opt, *data[0], warmup=1)
+    assert step._pack is m.engine().pack and not step._pack.capture_skips_cast
+    step(*data[1])
+    # new weights through load_state_dict (bumps the parameters' version counters), then one graphed and one eager step
+    torch.manual_seed(11)
+    other = {k: torch.randn_like(v) * 0.05 for k, v in m.state_dict().items()}
+    m.load_state_dict(other)
+    opt.reset_state()
+    loss_g = step(*data[2]).item()
+    m2, crit2, opt2 = _make()
+    m2.load_state_dict(other)
+    opt2.zero_grad()
+    loss_e = crit2(m2(data[2][0]), data[2][1])
+    loss_e.backward()
+    opt2.step()
+    assert loss_g == pytest.approx(loss_e.item(), rel=1e-5, abs=1e-6)
+    torch.testing.assert_close(m.engine().pack.flat, m2.engine().pack.flat, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(m.engine().pack.shadow.float(), m2.engine().pack.shadow.float(), rtol=0, atol=0)
+
+    m3, crit3, _ = _make()
+    stock = torch.optim.SGD(m3.parameters(), lr=5e-2, momentum=0.9)
+    assert GraphedStep(m3, crit3, stock, *data[0], warmup=1)._pack is None

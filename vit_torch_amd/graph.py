@@ -51,6 +51,7 @@ class GraphedStep:
         self.warm_out = None
         self.warm_loss = None
         self._lrs = None
+        self._pack = None
         self.recapture(self.warmup)
 
     def _eager(self):
@@ -78,15 +79,39 @@ class GraphedStep:
                 self.warm_out, self.warm_loss = out.detach().clone(), loss.detach().clone()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        # The engine's fp32 -> bf16 weight cast stays OUT of the graph when the captured optimizer is one of the fused ones
+        # over ALL of the pack's trainable parameters: those kernels write master and shadow in one pass, so inside the
+        # replay loop the shadow is always current, and __call__ checks the pack's version key eagerly before every replay
+        # (weights loaded or modified between replays are cast then).  Anything else keeps the recorded cast.
+        self._pack = self._vouched_pack()
+        if self._pack is not None:
+            self._pack.refresh_shadow()                # current at capture time (version check; usually a no-op)
+            self._pack.capture_skips_cast = True
         g = torch.cuda.CUDAGraph()
         self.optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(g):
-            out = self.model(self.x)
-            loss = self.criterion(out, self.y)
-            loss.backward()
-            self.optimizer.step()
+        try:
+            with torch.cuda.graph(g):
+                out = self.model(self.x)
+                loss = self.criterion(out, self.y)
+                loss.backward()
+                self.optimizer.step()
+        finally:
+            if self._pack is not None:
+                self._pack.capture_skips_cast = False
         self.graph, self.out, self.loss = g, out, loss
         self._lrs = [grp["lr"] for grp in self.optimizer.param_groups]
+
+    def _vouched_pack(self):
+        """The engine's ParamPack if the optimizer keeps its bf16 shadow current by itself, else None."""
+        from .optim import _FusedFlat
+        eng = self.model.engine() if hasattr(self.model, "engine") else None
+        pack = getattr(eng, "pack", None)
+        if pack is None or getattr(pack, "shadow", None) is None or not isinstance(self.optimizer, _FusedFlat):
+            return None
+        covered = {id(p) for grp in self.optimizer.param_groups for p in grp["params"]}
+        if any(p.requires_grad and id(p) not in covered for p in pack.params):
+            return None
+        return pack
 
     def __call__(self, x, y):
         if [grp["lr"] for grp in self.optimizer.param_groups] != self._lrs:
@@ -97,5 +122,7 @@ class GraphedStep:
             self.x.copy_(x, non_blocking=True)
         if y is not self.y:
             self.y.copy_(y, non_blocking=True)
+        if self._pack is not None:
+            self._pack.refresh_shadow()                # eager: casts only if a parameter was written since (version key)
         self.graph.replay()
         return self.loss

@@ -73,9 +73,14 @@ class ParamPack:
         if self.shadow is None:
             return
         key = self._version_key()
-        # inside a graph capture the cast is always recorded: a replay then re-derives the
-        # shadow from whatever the master holds (weights loaded between replays stay correct)
-        if getattr(self, "_shadow_key", None) != key or torch.cuda.is_current_stream_capturing():
+        # inside a graph capture the cast is recorded: a replay then re-derives the shadow from whatever the master
+        # holds (weights loaded between replays stay correct) — unless the capturing GraphedStep vouches for the shadow
+        # (`capture_skips_cast`: its optimizer writes master and shadow together, and it checks this same version key
+        # eagerly before every replay; round 3: the cast was 104 us of every replayed ViT-B/16 step)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing and getattr(self, "capture_skips_cast", False):
+            return
+        if getattr(self, "_shadow_key", None) != key or capturing:
             from . import ops
             ops.cast(self.flat, self.shadow)
             self._shadow_key = key
