@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VITMI_VERSION 106
+#define VITMI_VERSION 107
 
 enum { VITMI_F32 = 0, VITMI_BF16 = 1 };
 
@@ -301,6 +301,12 @@ int vitmi_token_mean(const void* x, float* out, const float* dout, void* dx, int
 /* fp32 -> bf16 shadow copy of the flat parameter buffer */
 int vitmi_cast(const void* src, int src_dtype, void* dst, int dst_dtype,
                int64_t n, void* stream);
+
+/* y[i] += a * x[i], fp32, 16-byte aligned (ABI 107): gradient accumulation — a second backward() before
+ * zero_grad() must ADD to .grad (torch.autograd's contract, /root/reference/utils_network.py:440-442 relies on
+ * zero_grad -> backward -> step); the engines overwrite their flat gradient buffer, so the wrapper saves the
+ * accumulated part and adds it back with this call */
+int vitmi_axpy(const float* x, float* y, float a, int64_t n, void* stream);
 
 /* out[m*ldo+n] = cast(x[m*ldx+n] * scale[n] * rowscale[m/rows_per_group]) (NULL -> 1):
  * strided row copy with optional per-column LayerScale / per-sample DropPath factor; also

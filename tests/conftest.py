@@ -19,3 +19,14 @@ def lib():
     if not _lib.LIB_PATH.exists():
         build.build()
     return _lib.load()
+
+
+@pytest.fixture(autouse=True)
+def _debug_switches_back_to_defaults():
+    """The library's vitmi_debug_* switches are process-wide: whatever a test flips (and however it ends — the
+    part after `yield` runs on failures too) is undone before the next test starts."""
+    yield
+    from vit_torch_amd import _lib
+    if _lib.LIB_PATH.exists():
+        import ctypes
+        ctypes.CDLL(str(_lib.LIB_PATH)).vitmi_debug_reset()

@@ -381,13 +381,13 @@ def cait_tiny_model(compute):
     from vit_torch_amd import cait_models
     return cait_models(img_size=32, patch_size=8, embed_dim=64, depth=2, num_heads=4, mlp_ratio=4, qkv_bias=True,
                        norm_layer=partial(nn.LayerNorm, eps=1e-6), init_scale=1e-1, depth_token_only=2,
-                       num_classes=10, compute_dtype=compute)
+                       num_classes=10, compute_dtype=compute, residual_dtype="auto")
 
 
 def swin_tiny_model(compute):
     from vit_torch_amd import SwinTransformer
     return SwinTransformer(img_size=56, patch_size=4, in_chans=3, num_classes=10, embed_dim=32, depths=[2, 2],
-                           num_heads=[2, 4], window_size=7, drop_path_rate=0.0, compute_dtype=compute)
+                           num_heads=[2, 4], window_size=7, drop_path_rate=0.0, compute_dtype=compute, residual_dtype="auto")
 
 
 ZERO_GRAD = ("proj_l.bias", "attn.k.bias")      # analytically zero gradients (softmax shift invariance)
@@ -442,15 +442,15 @@ def build_full_hip(name, compute):
     top, g = load(name)
     if name == "full_swin_tiny":
         m = VisionModelZoo.get_model("swin_tiny_patch4_window7_224", pretrained=False, classifier=None,
-                                     drop_path_rate=0.0, num_classes=10, compute_dtype=compute)
+                                     drop_path_rate=0.0, num_classes=10, compute_dtype=compute, residual_dtype="auto")
         m.head = nn.Linear(768, 10, bias=False)
     elif name == "full_cait_S24_224":
-        m = VisionModelZoo.get_model("cait_S24_224", pretrained=False, classifier=None, compute_dtype=compute)
+        m = VisionModelZoo.get_model("cait_S24_224", pretrained=False, classifier=None, compute_dtype=compute, residual_dtype="auto")
         m.head = nn.Linear(384, 10, bias=False)
         if hasattr(m, "head_dist"):
             m.head_dist = m.head
     else:                                             # oracle_dino_vitb16: the headline architecture
-        m = VisionModelZoo.get_model("dino_vitb16", pretrained=False, classifier=10, compute_dtype=compute)
+        m = VisionModelZoo.get_model("dino_vitb16", pretrained=False, classifier=10, compute_dtype=compute, residual_dtype="auto")
     seeded_init_(m, int(top["init_seed"]))
     if "gamma" in top:
         with torch.no_grad():

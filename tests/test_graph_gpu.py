@@ -9,7 +9,7 @@ def _make():
     from vit_torch_amd import CrossEntropyLoss, FusedSGD, VisionTransformer
     torch.manual_seed(5)
     m = VisionTransformer(img_size=32, patch_size=8, embed_dim=128, depth=3, num_heads=4, num_classes=10,
-                          compute_dtype="bf16").cuda()
+                          compute_dtype="bf16", residual_dtype="auto").cuda()
     m.head = torch.nn.Linear(128, 10, bias=False).cuda()
     return m, CrossEntropyLoss(), FusedSGD(m.parameters(), lr=5e-2, momentum=0.9)
 

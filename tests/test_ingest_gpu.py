@@ -82,7 +82,7 @@ def test_model_takes_patch_rows_in_place_of_the_image_tensor(lib):
     oy, ox, fl = aug.draw(8, 32, 32)
     torch.manual_seed(2)
     m = VisionTransformer(img_size=32, patch_size=8, embed_dim=64, depth=2, num_heads=2, num_classes=10,
-                          apply_head=True, compute_dtype="bf16").cuda()
+                          apply_head=True, compute_dtype="bf16", residual_dtype="auto").cuda()
     outs, grads = [], []
     for inp in (aug(img, oy, ox, fl), aug.patch_rows(img, 8, off_y=oy, off_x=ox, flip=fl)):
         m.zero_grad()

@@ -52,7 +52,7 @@ def test_swin_checkpoint_to_hip_forward(tmp_path, compute, tol):
     from vit_torch_amd import SwinTransformer, load_reference_checkpoint
     cfg = dict(img_size=56, patch_size=4, in_chans=3, num_classes=10, embed_dim=32, depths=[2, 2], num_heads=[2, 4],
                window_size=7, drop_path_rate=0.0)
-    m = SwinTransformer(**cfg, compute_dtype=compute).cuda()
+    m = SwinTransformer(**cfg, compute_dtype=compute, residual_dtype="auto").cuda()
     x = x_for(56)
     for i, seed in enumerate((5, 6)):
         ref = seeded_init_(swin_ref.SwinTransformer(**cfg), seed)
@@ -93,7 +93,7 @@ def test_network_fit_writes_the_reference_log_layout_on_the_gpu(tmp_path):
     from vit_torch_amd.stats import RunLog, probe_hardware
     ref_log = json.load(open(os.path.join(HERE, "golden", "ref_stats_log.json")))
     m = VisionTransformer(img_size=32, patch_size=8, embed_dim=64, depth=2, num_heads=2, apply_head=True,
-                          compute_dtype="bf16")
+                          compute_dtype="bf16", residual_dtype="auto")
     m.head = VisionModelZoo.get_classifier_head(64, 10)
     g = torch.Generator("cpu").manual_seed(0)
     train = [(torch.randn(8, 3, 32, 32, generator=g), torch.randint(0, 10, (8,), generator=g)) for _ in range(3)]

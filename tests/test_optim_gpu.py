@@ -16,7 +16,7 @@ SMALL = dict(img_size=32, patch_size=16, in_chans=3, embed_dim=64, depth=1, num_
 def _model(compute="fp32"):
     from vit_torch_amd import VisionTransformer
     torch.manual_seed(3)
-    m = VisionTransformer(**SMALL, num_classes=10, apply_head=True, compute_dtype=compute).cuda()
+    m = VisionTransformer(**SMALL, num_classes=10, apply_head=True, compute_dtype=compute, residual_dtype="auto").cuda()
     m.engine()
     return m
 

@@ -109,7 +109,7 @@ def small_pair(seed, compute="bf16"):
     ref = vit_ref.VisionTransformer(**SMALL, apply_head=True)
     ref.head = vit_ref.get_classifier_head(SMALL["embed_dim"], 10)
     vit_ref.seeded_init_(ref, seed)
-    m = VisionTransformer(**SMALL, apply_head=True, compute_dtype=compute)
+    m = VisionTransformer(**SMALL, apply_head=True, compute_dtype=compute, residual_dtype="auto")
     m.head = VisionModelZoo.get_classifier_head(SMALL["embed_dim"], 10)
     m.load_state_dict(ref.state_dict(), strict=True)
     return ref, m.cuda()

@@ -311,7 +311,7 @@ def test_deferred_folds_leave_every_gradient_bit_identical(monkeypatch):
     grads = []
     for flag in ("0", "1"):
         monkeypatch.setenv("VITMI_DEFER_FOLDS", flag)
-        m = VisionTransformer(**cfg, apply_head=True, compute_dtype="bf16")
+        m = VisionTransformer(**cfg, apply_head=True, compute_dtype="bf16", residual_dtype="auto")
         m.head = vit_ref.get_classifier_head(64, 10)
         m.load_state_dict(ref.state_dict())
         m = m.cuda()

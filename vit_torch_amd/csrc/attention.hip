@@ -26,6 +26,7 @@
 // 7 MFMA products instead of the minimal 5, but no dQ reduction across waves.
 // hd = 64: the softmax's VALU work (exp, max, sum, cvt) outweighs the MFMAs, so
 // masks are applied only to ragged blocks and the scale is folded into exp2.
+#include <atomic>
 #include "common.h"
 
 namespace {
@@ -1034,7 +1035,7 @@ static int check_attn(const void* qkv, int dtype, int64_t B, int64_t N, int64_t 
 int attn_fwd_f32(const float* qkv, float* out, float* lse, int64_t B, int64_t N, int64_t H, int64_t hd, float scale, hipStream_t stream);
 int attn_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int64_t B, int64_t N, int64_t H, int64_t hd, float scale, float* delta, hipStream_t stream);
 
-static int g_attn_fwd_waves = 0;     // diagnostic hook: waves (32 queries each) per forward workgroup, 0 = default
+static std::atomic<int> g_attn_fwd_waves{0};     // diagnostic hook: waves (32 queries each) per forward workgroup, 0 = default
 extern "C" void vitmi_debug_attn_fwd_waves(int n) { g_attn_fwd_waves = n; }
 
 extern "C" int vitmi_attn_fwd(const void* qkv, void* out, float* lse, int dtype, int64_t B,
@@ -1063,7 +1064,7 @@ extern "C" int vitmi_attn_fwd(const void* qkv, void* out, float* lse, int dtype,
   // of one overlaps the softmax of the others; measured 9 % faster than one 7-wave
   // workgroup per (image, head) at N = 197 although K/V are then staged twice
   int nw = attn_waves(N);
-  const int cap = g_attn_fwd_waves > 0 ? g_attn_fwd_waves : 4;
+  const int fw_ = g_attn_fwd_waves; const int cap = fw_ > 0 ? fw_ : 4;
   if (cap < nw) nw = cap;
   dim3 grid((unsigned)((N + 32 * nw - 1) / (32 * nw)), (unsigned)(B * H));
   if (hd == 64) {
@@ -1080,10 +1081,10 @@ extern "C" size_t vitmi_attn_bwd_workspace(int64_t B, int64_t N, int64_t H) {
   return (size_t)(B * N * H) * sizeof(float);
 }
 
-static unsigned long long* g_attn_dbg = nullptr;
+static std::atomic<unsigned long long*> g_attn_dbg{nullptr};
 
 extern "C" void vitmi_debug_attn_stamps(void* p) { g_attn_dbg = reinterpret_cast<unsigned long long*>(p); }
-static int g_attn_bwd_mode = -1;     // diagnostic / test hook: 0 = dkdv + dq kernels, 1 = fused where possible
+static std::atomic<int> g_attn_bwd_mode{-1};     // diagnostic / test hook: 0 = dkdv + dq kernels, 1 = fused where possible
 extern "C" void vitmi_debug_attn_bwd(int mode) { g_attn_bwd_mode = mode; }
 static bool attn_bwd_fused_ok(int64_t N, int64_t hd) {
   if (g_attn_bwd_mode == 0) return false;
@@ -1124,7 +1125,7 @@ extern "C" int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout
       if (int rc_ = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024, "attn_bwd")) return rc_; \
       hipLaunchKernelGGL(kern, dim3((unsigned)grid_f), dim3(64 * nw), lds, stream, (const bf16*)qkv,     \
                          (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, (int)N, (int)H,          \
-                         (int)(B * H), scale, scale * LOG2E, dbias_part, g_attn_dbg);                    \
+                         (int)(B * H), scale, scale * LOG2E, dbias_part, g_attn_dbg.load());                    \
     } while (0)
     if (hd == 64) { if (dbias_part) LAUNCH_FUSED(64, true); else LAUNCH_FUSED(64, false); }
     else          { if (dbias_part) LAUNCH_FUSED(32, true); else LAUNCH_FUSED(32, false); }
@@ -1155,4 +1156,11 @@ extern "C" int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout
   else          { if (dbias_part) LAUNCH_BWD(32, true); else LAUNCH_BWD(32, false); }
 #undef LAUNCH_BWD
   return rc;
+}
+
+// every diagnostic switch of this file back to its default (vitmi_debug_reset, core.cpp)
+void vitmi_debug_reset_attention() {
+  g_attn_fwd_waves = 0;
+  g_attn_dbg = nullptr;
+  g_attn_bwd_mode = -1;
 }

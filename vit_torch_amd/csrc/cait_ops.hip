@@ -8,6 +8,7 @@
 //  * column sum of an element-wise product (LayerScale gradient).
 // Correctness-first versions: the score tensors S, P, P' live in HBM between the batched
 // MFMA products (gemm.hip, batched form) and these kernels.  H <= 8, row length <= 256.
+#include <atomic>
 #include "common.h"
 
 namespace {
@@ -606,7 +607,7 @@ extern "C" size_t vitmi_th_softmax_bwd_workspace(int64_t B, int64_t H, int64_t N
   return (size_t)th_bwd_blocks(B * N) * (size_t)(2 * H * H + 2 * H) * sizeof(float);
 }
 
-static int g_th_mfma = 1;   // diagnostic / test hook: 0 = parameter gradients on per-lane FMAs only
+static std::atomic<int> g_th_mfma{1};   // diagnostic / test hook: 0 = parameter gradients on per-lane FMAs only
 extern "C" void vitmi_debug_th_mfma(int on) { g_th_mfma = on; }
 
 extern "C" int vitmi_th_softmax_bwd(const void* S, const void* P, const void* dPm, const float* Wl,
@@ -694,4 +695,9 @@ extern "C" int vitmi_colsum_mul(const void* x, int x_dtype, int64_t ldx, const v
   int rc = vitmi_check_launch("colsum_mul_partial_kernel");
   if (rc) return rc;
   return vitmi_reduce_rows(part, S, N, N, out, stream);
+}
+
+// every diagnostic switch of this file back to its default (vitmi_debug_reset, core.cpp)
+void vitmi_debug_reset_cait() {
+  g_th_mfma = 1;
 }

@@ -54,6 +54,28 @@ int vitmi_cu_count() {
 // test / profiling hook (not part of the ABI): -1 = follow each call's launch_flags (default), 0 = force
 // one tile / pair per workgroup, 1 = force the persistent grids
 static std::atomic<int> g_persist_override{-1};
+void vitmi_debug_reset_attention();
+void vitmi_debug_reset_cait();
+void vitmi_debug_reset_gemm();
+void vitmi_debug_reset_gemm_fast();
+void vitmi_debug_reset_gemm_fast2();
+void vitmi_debug_reset_gemm_small();
+void vitmi_debug_reset_layernorm();
+void vitmi_debug_reset_swin();
+// all vitmi_debug_* switches back to their defaults.  They are process-wide std::atomic<int>s read at launch time
+// (diagnostics and A/B hooks, not part of include/vitmi.h); tests/conftest.py calls this after EVERY test, so a test that
+// fails between a set and its reset cannot leave the next one on another kernel
+extern "C" void vitmi_debug_reset(void) {
+  g_persist_override.store(-1, std::memory_order_relaxed);
+  vitmi_debug_reset_attention();
+  vitmi_debug_reset_cait();
+  vitmi_debug_reset_gemm();
+  vitmi_debug_reset_gemm_fast();
+  vitmi_debug_reset_gemm_fast2();
+  vitmi_debug_reset_gemm_small();
+  vitmi_debug_reset_layernorm();
+  vitmi_debug_reset_swin();
+}
 extern "C" void vitmi_debug_gemm_persist(int on) { g_persist_override.store(on < 0 ? -1 : (on != 0), std::memory_order_relaxed); }
 int vitmi_persist_on(int launch_flags) {
   const int o = g_persist_override.load(std::memory_order_relaxed);

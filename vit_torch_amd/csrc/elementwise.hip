@@ -25,6 +25,19 @@ __global__ void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, in
     dst[i] = from_f32<TD>(to_f32(src[i]));
 }
 
+// ------------------------------------------------------------------ axpy --
+// y += a * x (fp32): gradient accumulation over the flat gradient buffer when backward() runs a
+// second time before zero_grad() (torch's contract; the engines overwrite their buffer)
+__global__ void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, float a, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n4 = n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4), w = *reinterpret_cast<const f32x4*>(y + i * 4);
+    *reinterpret_cast<f32x4*>(y + i * 4) = w + a * v;
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] += a * x[i];
+}
+
 // ------------------------------------------------------------ scale_cast --
 // out[m][n] = cast(x[m][n] * scale[n])  (scale may be NULL): the GEMM-operand copy of a
 // residual-stream gradient entering a LayerScale branch
@@ -421,6 +434,14 @@ extern "C" int vitmi_cast(const void* src, int sd, void* dst, int dd, int64_t n,
   else if (sd == VITMI_BF16 && dd == VITMI_BF16) hipLaunchKernelGGL((cast_kernel<bf16, bf16>), dim3(grid), dim3(EW_BLOCK), 0, stream, (const bf16*)src, (bf16*)dst, n);
   else return vitmi_fail(VITMI_E_DTYPE, "cast: bad dtypes %d -> %d", sd, dd);
   return vitmi_check_launch("cast_kernel");
+}
+
+extern "C" int vitmi_axpy(const float* x, float* y, float a, int64_t n, void* stream_) {
+  VITMI_REQUIRE(x && y && n > 0, VITMI_E_BADARG, "axpy: null pointer or n <= 0");
+  VITMI_REQUIRE(is_aligned(x, 16) && is_aligned(y, 16), VITMI_E_ALIGN, "axpy: pointers must be 16-byte aligned");
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  hipLaunchKernelGGL(axpy_kernel, dim3(ew_grid(n / 4 + 1)), dim3(EW_BLOCK), 0, stream, x, y, a, n);
+  return vitmi_check_launch("axpy_kernel");
 }
 
 extern "C" int vitmi_scale_cast(const void* x, int x_dtype, int64_t ldx, const float* scale,

@@ -5,6 +5,7 @@
 // (v_mfma_f32_32x32x2_f32: exact fp32 fma chain in k order — the parity mode).
 // It is the correctness workhorse (classifier head, ragged shapes, fp32 mode);
 // the aligned hot shapes go to gemm_fast.hip.
+#include <atomic>
 #include "epilogue.h"
 
 bool gemm_fast_supported(const GemmArgs& g, int in_bf16);
@@ -15,10 +16,10 @@ size_t gemm_fast_workspace(const GemmArgs& g);
 // s_memtime stamps of its R / M phases and barrier waits into this buffer
 // debug hook: prefetched tiles of the persistent walk wait for EVERYTHING (vmcnt(0)) before their first slab is read,
 // instead of the counted wait that relies on the epilogue issuing at least E_MIN stores; results must be bit-identical
-static int g_gemm_strict_wait = 0;
+static std::atomic<int> g_gemm_strict_wait{0};
 extern "C" void vitmi_debug_gemm_strict_wait(int on) { g_gemm_strict_wait = on != 0; }
-static unsigned long long* g_gemm_dbg = nullptr;
-static int g_gemm_dbg_blocks = 64;
+static std::atomic<unsigned long long*> g_gemm_dbg{nullptr};
+static std::atomic<int> g_gemm_dbg_blocks{64};
 extern "C" void vitmi_debug_gemm_stamps(unsigned long long* buf) { g_gemm_dbg = buf; g_gemm_dbg_blocks = 64; }
 // timeline of the first `blocks` workgroups: buf holds 64 + 4 * blocks entries
 extern "C" void vitmi_debug_gemm_timeline(unsigned long long* buf, int blocks) { g_gemm_dbg = buf; g_gemm_dbg_blocks = blocks; }
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
 
 }  // namespace
 
-static int g_skinny = 1;             // diagnostic / test hook: 0 = the head's products stay on the 64x64-tile kernel
+static std::atomic<int> g_skinny{1};             // diagnostic / test hook: 0 = the head's products stay on the 64x64-tile kernel
 extern "C" void vitmi_debug_gemm_skinny(int on) { g_skinny = on != 0; }
 // which fp32 problems take the skinny kernel: -1 = none
 static int gemm_skinny_form(const GemmArgs& g, int in_bf16) {
@@ -244,13 +245,13 @@ static int gemm_skinny_launch(const GemmArgs& g, int form, hipStream_t stream) {
 // Automatic: `nt` for the wide activation outputs that are written once and read by a LATER kernel
 // (qkv, fc1's two outputs, the data gradients: >= 64 MB), plain for everything else (the residual
 // stream's new rows are read back at once by the LayerNorm that follows, weight-gradient tiles are small).
-static int g_c_policy = -1;
+static std::atomic<int> g_c_policy{-1};
 extern "C" void vitmi_debug_gemm_store_policy(int p) { g_c_policy = p; }
-static int g_nt_min_mb = 64;         // diagnostic hook: outputs / side inputs of at least this many MB take the nt policy
+static std::atomic<int> g_nt_min_mb{64};         // diagnostic hook: outputs / side inputs of at least this many MB take the nt policy
 extern "C" void vitmi_debug_gemm_nt_min_mb(int mb) { g_nt_min_mb = mb > 0 ? mb : 64; }
-static int g_side_nt = -1;           // diagnostic hook: -1 = automatic (wide side inputs), 0 / 1 forced
+static std::atomic<int> g_side_nt{-1};           // diagnostic hook: -1 = automatic (wide side inputs), 0 / 1 forced
 extern "C" void vitmi_debug_gemm_side_nt(int v) { g_side_nt = v; }
-static int g_side_depth = 3;         // diagnostic hook: strips of the epilogue's side input in flight (bf16 outputs): 1 or 3
+static std::atomic<int> g_side_depth{3};         // diagnostic hook: strips of the epilogue's side input in flight (bf16 outputs): 1 or 3
 extern "C" void vitmi_debug_gemm_side_depth(int d) { g_side_depth = d >= 3 ? 3 : 1; }
 static int side_policy(const vitmi_gemm_desc* d) {
   if (g_side_nt >= 0) return g_side_nt;
@@ -352,7 +353,7 @@ static int build_args(const vitmi_gemm_desc* d, GemmArgs* out) {
 
 int gemm_small_form(const GemmArgs& g, int in_bf16);
 int gemm_small_launch(const GemmArgs& g, int form, hipStream_t stream);
-static int g_small_override = -1;    // diagnostic / test hook: 0 = never, 1 = also when impl == GENERIC, -1 = default
+static std::atomic<int> g_small_override{-1};    // diagnostic / test hook: 0 = never, 1 = also when impl == GENERIC, -1 = default
 extern "C" void vitmi_debug_gemm_small(int mode) { g_small_override = mode; }
 static bool small_lds_ok(const GemmArgs& g, int form) {
   if (form == 0) return ((g.N + 15) / 16 * 16) * (64 * 2 + 16) <= 96 * 1024;
@@ -378,7 +379,7 @@ extern "C" size_t vitmi_gemm_workspace(const vitmi_gemm_desc* d) {
 size_t gemm_fast_pair_workspace(const GemmArgs& a, const GemmArgs& b);
 int gemm_fast_pair_launch(const GemmArgs& a, const GemmArgs& b, void* ws, size_t ws_bytes, hipStream_t stream);
 
-static int g_pair = 1;               // diagnostic hook: 0 = never pair (two launches), for A/B inside the step
+static std::atomic<int> g_pair{1};               // diagnostic hook: 0 = never pair (two launches), for A/B inside the step
 extern "C" void vitmi_debug_gemm_pair(int on) { g_pair = on != 0; }
 static bool pair_args(const vitmi_gemm_desc* d0, const vitmi_gemm_desc* d1, GemmArgs* a, GemmArgs* b) {
   if (!g_pair) return false;
@@ -430,4 +431,18 @@ extern "C" int vitmi_gemm(const vitmi_gemm_desc* d, void* stream_) {
   if (in_bf16) hipLaunchKernelGGL(gemm_generic_kernel<bf16>, grid, dim3(256), 0, stream, g);
   else hipLaunchKernelGGL(gemm_generic_kernel<float>, grid, dim3(256), 0, stream, g);
   return vitmi_check_launch("gemm_generic_kernel");
+}
+
+// every diagnostic switch of this file back to its default (vitmi_debug_reset, core.cpp)
+void vitmi_debug_reset_gemm() {
+  g_gemm_strict_wait = 0;
+  g_gemm_dbg = nullptr;
+  g_gemm_dbg_blocks = 64;
+  g_skinny = 1;
+  g_c_policy = -1;
+  g_nt_min_mb = 64;
+  g_side_nt = -1;
+  g_side_depth = 3;
+  g_small_override = -1;
+  g_pair = 1;
 }

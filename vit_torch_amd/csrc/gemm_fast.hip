@@ -22,6 +22,7 @@
 // Block -> tile map is XCD-aware (8 XCDs, private L2s): each XCD walks a
 // contiguous run of tiles, n fastest, so the A panel of a row of tiles and the
 // whole weight matrix stay in that XCD's L2.
+#include <atomic>
 #include <type_traits>
 #include "gemm_tile.h"
 
@@ -1075,7 +1076,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, E
 }
 
 // split-K plan for a problem with `tiles` output tiles and `nt` k-steps
-static int g_splitk_target = 256;
+static std::atomic<int> g_splitk_target{256};
 inline void splitk_plan(int tiles, int nt, int* splits, int* ksps) {
   int s = 1;
   if (tiles <= 128 && nt >= 16) {
@@ -1124,7 +1125,7 @@ __global__ __launch_bounds__(256) void tail_epilogue_kernel(const float* __restr
   }
 }
 
-static int g_tail_override = -1;
+static std::atomic<int> g_tail_override{-1};
 // diagnostic / test hook: 0 = never split the tail, 1 = whenever the shape allows, -1 = default heuristic
 extern "C" void vitmi_debug_gemm_tail(int mode) { g_tail_override = mode; }
 constexpr int TAIL_SPLITS = 3;
@@ -1158,18 +1159,18 @@ static bool tail_plan(const GemmArgs& g, int nwg, int* rem, int* splits, int* ks
 // then reads back at the 40-65 GB/s a single CU gets for freshly written lines (12-19 us, on 79 of the 256 CUs), behind an
 // agent-scope release that writes back 256 KB of dirty lines per slice — the guide's own sizing rule (in-launch combine
 // pays for a few tens of KB per tile, not hundreds).  The separate finisher is 1 264 blocks over the whole chip.
-static int g_tail_fixup = 0;
+static std::atomic<int> g_tail_fixup{0};
 extern "C" void vitmi_debug_gemm_tail_fixup(int on) { g_tail_fixup = on != 0; }
 
-static int g_rfold_override = -1;
+static std::atomic<int> g_rfold_override{-1};
 // diagnostic / test hook: 0 = epilogue reads the residual (round-1 behaviour), 1 / -1 = fold it in
 extern "C" void vitmi_debug_gemm_rfold(int mode) { g_rfold_override = mode; }
 
 // diagnostic hook / default of the start stagger: permille of an estimated tile time (0 = off) and phases
-static int g_stagger_permille = 700, g_stagger_phases = 4;     // swept inside the ViT-B/16 step (tools/sweep_bench.sh): 34.53 -> 33.98 ms
+static std::atomic<int> g_stagger_permille{700}, g_stagger_phases{4};     // swept inside the ViT-B/16 step (tools/sweep_bench.sh): 34.53 -> 33.98 ms
 extern "C" void vitmi_debug_gemm_stagger(int permille) { g_stagger_permille = permille; }
 extern "C" void vitmi_debug_gemm_stagger_phases(int n) { g_stagger_phases = n > 0 ? n : 1; }
-static int g_pipe_override = -1;
+static std::atomic<int> g_pipe_override{-1};
 // diagnostic / test hook: force the main-loop variant (0, 1, 2) or -1 = automatic
 extern "C" void vitmi_debug_gemm_pipe(int mode) { g_pipe_override = mode; }
 
@@ -1226,7 +1227,7 @@ static int persistent_grid(int nwg, int launch_flags) {
 // Column-band width of the tile order (tile_mn): bands only where the whole B matrix does not fit an
 // XCD's L2 beside the streaming operands (N x K x 2 B > 3 MiB) and there are rows enough to fill the
 // XCDs inside a band; the band is the widest divisor-free choice whose B panels take <= 2 MiB.
-static int g_band_override = -1;     // diagnostic hook: -1 = automatic, 0 = row-major, n = bands of n column tiles
+static std::atomic<int> g_band_override{-1};     // diagnostic hook: -1 = automatic, 0 = row-major, n = bands of n column tiles
 extern "C" void vitmi_debug_gemm_band(int n) { g_band_override = n; }
 static int band_for(const GemmArgs& g, int tiles_m, int tiles_n) {
   if (g_band_override >= 0) return g_band_override;
@@ -1358,7 +1359,7 @@ int gemm_fast2_launch(const GemmArgs& g, hipStream_t s);
 
 // diagnostic hook: workgroups a split-K launch of the 256x256 kernel aims at (default 256)
 extern "C" void vitmi_debug_gemm_splitk_target(int n) { g_splitk_target = n > 0 ? n : 256; }
-static int g_tile_override = -1;
+static std::atomic<int> g_tile_override{-1};
 // diagnostic / test hook: 1 = 256x256 tiles (one 8-wave workgroup per CU),
 // 2 = 256x128 tiles (two 4-wave workgroups per CU), -1 = default
 extern "C" void vitmi_debug_gemm_tile(int mode) { g_tile_override = mode; }
@@ -1456,9 +1457,12 @@ static int gemm_fast_launch_whole(const GemmArgs& g, hipStream_t s) {
 static bool pair_ok(const GemmArgs& a, const GemmArgs& b) {
   auto plain = [](const GemmArgs& g) {
     return !g.a_km && !g.b_km && g.e.mode == VITMI_EPI_STORE && !g.e.c_bf16 && !g.e.bias && !g.e.accumulate &&
-           g.e.alpha == 1.f && g.batch == 1 && (g.M % BM) == 0 && (g.N % BN) == 0 && (g.K % BK) == 0;
+           g.e.alpha == 1.f && g.batch == 1 && (g.M % BM) == 0 && (g.N % BN) == 0 && (g.K % BK) == 0 &&
+           // nothing the paired launch would silently drop (its main kernel stores raw partial tiles, its reduce applies
+           // the plain store): descriptors that carry any of these take the two-call fallback, which honours or rejects them
+           !g.e.colsum_part && !g.e.C2 && !g.e.rowscale && !g.e.gamma && !g.e.R && !g.e.AUX;
   };
-  return plain(a) && plain(b) && a.K == b.K;
+  return plain(a) && plain(b) && a.K == b.K && a.launch_flags == b.launch_flags;
 }
 size_t gemm_fast_pair_workspace(const GemmArgs& a, const GemmArgs& b) {
   if (!pair_ok(a, b)) return 0;
@@ -1500,4 +1504,17 @@ int gemm_fast_pair_launch(const GemmArgs& a_in, const GemmArgs& b, void* ws_, si
 int gemm_fast_launch(const GemmArgs& g, hipStream_t s) {
   if (use_tile2(g)) return gemm_fast2_launch(g, s);
   return gemm_fast_launch_whole(g, s);
+}
+
+// every diagnostic switch of this file back to its default (vitmi_debug_reset, core.cpp)
+void vitmi_debug_reset_gemm_fast() {
+  g_splitk_target = 256;
+  g_tail_override = -1;
+  g_tail_fixup = 0;
+  g_rfold_override = -1;
+  g_stagger_permille = 700;
+  g_stagger_phases = 4;
+  g_pipe_override = -1;
+  g_band_override = -1;
+  g_tile_override = -1;
 }

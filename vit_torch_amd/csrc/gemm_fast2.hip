@@ -17,6 +17,7 @@
 //   issue LDS-DMA of slab j+2 into the stage slab j-1 occupied
 //   12 fragment reads of slab j, 32 MFMAs
 // LDS images, swizzles, epilogue: as gemm_fast.hip (gemm_tile.h).
+#include <atomic>
 #include <type_traits>
 #include "gemm_tile.h"
 
@@ -361,7 +362,7 @@ inline int splitk_reduce2_waves(int64_t total4, int splits) {
 // weight gradients) that traffic outweighs the second workgroup's latency hiding (measured,
 // whole step: target 512 / 384 / 256 / 192 / 128 -> CaiT-S24 19.74 / 19.59 / 19.37 / 19.59 /
 // 20.43 ms, Swin-T 16.33 / - / 16.05 / 16.29 / 17.04 ms).
-static int g_splitk2_target = 256;
+static std::atomic<int> g_splitk2_target{256};
 inline void splitk_plan2(int tiles, int nt, int* splits, int* ksps) {
   int s = 1;
   if (tiles <= 256 && nt >= 16) {
@@ -439,4 +440,9 @@ int gemm_fast2_launch(const GemmArgs& g, hipStream_t s) {
   }
 #undef GO
   return vitmi_fail(VITMI_E_SHAPE, "gemm_fast2: combination not built");
+}
+
+// every diagnostic switch of this file back to its default (vitmi_debug_reset, core.cpp)
+void vitmi_debug_reset_gemm_fast2() {
+  g_splitk2_target = 256;
 }

@@ -10,6 +10,7 @@
 //   FORM 2  C[j][n] = alpha sum_k S[k][j] Y[k][n]      (!a_kmajor, !b_kmajor) K = tokens
 // v_mfma_f32_16x16x32_bf16, D[m][n]: the lane owns output column n = lane & 15 (consecutive
 // lanes write consecutive elements of a C row), rows 4*(lane >> 4) + r.
+#include <atomic>
 #include "common.h"
 #include "epilogue.h"
 
@@ -280,7 +281,7 @@ inline size_t small_lds(int form, int M, int N, int K) {
 
 }  // namespace
 
-static int g_small_parts = 0;     // diagnostic hook: workgroups per problem, 0 = heuristic
+static std::atomic<int> g_small_parts{0};     // diagnostic hook: workgroups per problem, 0 = heuristic
 extern "C" void vitmi_debug_gemm_small_parts(int n) { g_small_parts = n; }
 
 // which batched bf16 problems take this kernel (plain store epilogue only)
@@ -327,4 +328,9 @@ int gemm_small_launch(const GemmArgs& g, int form, hipStream_t stream) {
   else SMALL_GO(2);
 #undef SMALL_GO
   return vitmi_check_launch("gemm_small_kernel");
+}
+
+// every diagnostic switch of this file back to its default (vitmi_debug_reset, core.cpp)
+void vitmi_debug_reset_gemm_small() {
+  g_small_parts = 0;
 }

@@ -2,6 +2,7 @@
 // fp32 statistics, 16-B (fp32) / 8-B (bf16) vector accesses.  HBM-bound:
 // fwd moves (sizeof(X)+sizeof(Y))*D bytes per row, bwd
 // (sizeof(dY)+sizeof(X)+2*sizeof(G)+sizeof(Gb))*D.
+#include <atomic>
 #include <initializer_list>
 #include "common.h"
 
@@ -386,7 +387,7 @@ inline Ln8Cfg ln8_cfg(int64_t D) {
   if (D <= 1536) return {64, 3};
   return {64, 4};
 }
-static int g_ln8 = 1;     // diagnostic hook (vitmi_debug_ln8): 0 = the 4-element kernels everywhere
+static std::atomic<int> g_ln8{1};     // diagnostic hook (vitmi_debug_ln8): 0 = the 4-element kernels everywhere
 
 inline int ln_nv(int64_t D) { return D <= 512 ? 2 : D <= 768 ? 3 : D <= 1024 ? 4 : LN_MAXV; }
 // grid-stride blocks of the backward kernel: 4 per CU while the row fits few registers
@@ -610,4 +611,9 @@ extern "C" int vitmi_layernorm_bwd_deferred(const void* dy, int dy_dtype, int64_
   if (rc) return rc;
   ln_fold_desc(fold, part, nblk, D, dgamma, dbeta, gsum);
   return 0;
+}
+
+// every diagnostic switch of this file back to its default (vitmi_debug_reset, core.cpp)
+void vitmi_debug_reset_layernorm() {
+  g_ln8 = 1;
 }

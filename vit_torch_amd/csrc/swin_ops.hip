@@ -10,6 +10,7 @@
 // Two implementations: fp32 vector kernels (any hd <= 64, both dtypes: the parity mode) with
 // one workgroup per (window, head), and the bf16 MFMA kernels for hd = 32 (every Swin variant
 // at window 7) with one WAVE per (window, head) — "MFMA path" below.
+#include <atomic>
 #include "common.h"
 
 namespace {
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(const bf16* __re
 //                                         from [row][d] images the same way
 //   dQ^T += K^T dS^T                      B operand = the dS accumulators themselves
 constexpr int TP = 160;                // pitch of the [64 q][64 key] bf16 tile
-static int g_win_bwd_prefetch = 1;     // diagnostic hook (vitmi_debug_win_bwd_prefetch): L2 prefetch of a wave's next window
+static std::atomic<int> g_win_bwd_prefetch{1};     // diagnostic hook (vitmi_debug_win_bwd_prefetch): L2 prefetch of a wave's next window
 constexpr int WIN_BWD_LDS = 3 * 64 * WP + 64 * TP;     // Q, K, dO images + tile, per wave
 
 __device__ __forceinline__ void win_store_T(bf16* dst, const f32x4& acc, float mul, int g) {
@@ -710,7 +711,7 @@ __global__ void token_mean_bwd_kernel(const float* __restrict__ dout, T* __restr
 
 }  // namespace
 
-static int g_win_mfma = -1;   // diagnostic / test hook: 0 = fp32 vector kernels only, else MFMA where it applies
+static std::atomic<int> g_win_mfma{-1};   // diagnostic / test hook: 0 = fp32 vector kernels only, else MFMA where it applies
 extern "C" void vitmi_debug_win_attn_mfma(int mode) { g_win_mfma = mode; }
 
 static int win_check(int64_t Bw, int64_t H, int64_t N, int64_t hd, int64_t Himg, int64_t Wimg, int64_t ws, int64_t shift, const char* who) {
@@ -863,4 +864,10 @@ extern "C" int vitmi_token_mean(const void* x, float* out, const float* dout, vo
     return vitmi_check_launch("token_mean_bwd_kernel");
   }
   return 0;
+}
+
+// every diagnostic switch of this file back to its default (vitmi_debug_reset, core.cpp)
+void vitmi_debug_reset_swin() {
+  g_win_bwd_prefetch = 1;
+  g_win_mfma = -1;
 }

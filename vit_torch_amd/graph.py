@@ -38,6 +38,12 @@ class GraphedStep:
             raise VitmiError("GraphedStep needs example inputs on the GPU")
         eng = model.engine() if hasattr(model, "engine") else None
         red = getattr(eng, "reducer", None) if eng is not None else None
+        if red is not None and (red.world > 1 or red.force):
+            import torch.distributed as dist
+            backend = dist.get_backend(red.group) if dist.is_initialized() else None
+            if backend != "nccl":
+                raise VitmiError(f"GraphedStep can capture the gradient exchange on RCCL ('nccl') only: a {backend!r} "
+                                 "all_reduce of device tensors is not capturable — run the step eagerly")
         if red is not None and warmup < 1:
             raise VitmiError("GraphedStep with a GradReducer needs warmup >= 1: the RCCL communicator must be "
                              "created by an eager exchange before the capture starts")

@@ -29,7 +29,9 @@ class _HeadFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         head = ctx.head
+        held = head._pack.begin_backward()      # torch's accumulation contract (packing.ParamPack.begin_backward)
         dx = head._backward(dout, ctx.need_dx)
+        head._pack.end_backward(held)
         grads = []
         for p, gv in zip(head._pack.params, head._pack.fresh_grad_views()):
             if not p.requires_grad:

@@ -310,6 +310,14 @@ def cast(src, dst):
     return dst
 
 
+def axpy(x, y, a=1.0):
+    """y += a * x (fp32, contiguous): gradient accumulation over a span of the flat gradient buffer."""
+    _need_cuda(x, y)
+    assert x.dtype == y.dtype == torch.float32 and x.numel() == y.numel() and x.is_contiguous() and y.is_contiguous()
+    check(load().vitmi_axpy(x.data_ptr(), y.data_ptr(), float(a), x.numel(), _stream()), "vitmi_axpy")
+    return y
+
+
 def patchify(x, out, p, cls_rows):
     """x [B,C,H,W] fp32 (any strides) -> out [B*(cls_rows+gh*gw), ld] with ld >= C*p*p; the columns
     beyond C*p*p are written as zeros (K padding for the tile GEMM)."""

@@ -53,11 +53,16 @@ class _StepCounters:
 
     def __init__(self):
         self.ticks = {}          # (start, end) -> tensor
+        self._runs_key = None    # the `runs` the current pieces were cut for
 
     def spans(self, runs, device):
         """[(start, end, tick)] covering `runs`."""
-        if all(r in self.ticks for r in runs) and len(runs) == len(self.ticks):
-            return [(s, e, self.ticks[(s, e)]) for s, e in runs]
+        # unchanged runs -> the existing pieces, no read-back, the SAME tick tensors (a captured HIP graph keeps advancing
+        # them).  The pieces may be finer than the runs (a run cut where the step count changes after an unfreeze), so
+        # the test is on the runs the pieces were cut for, not on the dictionary's keys (ADVICE r03: the key test never
+        # passed again after a cut, and every later step paid a host sync and fresh tick tensors)
+        if self._runs_key == tuple(runs) and self.ticks:
+            return [(s, e, t) for (s, e), t in sorted(self.ticks.items())]
         old = sorted((s, e, float(t.item())) for (s, e), t in self.ticks.items())    # rare: one sync
 
         def count_at(i):
@@ -78,6 +83,7 @@ class _StepCounters:
                     piece_lo, piece_c = a, c
             new[(piece_lo, e)] = piece_c
         self.ticks = {k: torch.full((1,), c, dtype=torch.float32, device=device) for k, c in new.items()}
+        self._runs_key = tuple(runs)
         return [(s, e, t) for (s, e), t in sorted(self.ticks.items())]
 
 

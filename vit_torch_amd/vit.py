@@ -80,13 +80,14 @@ class VisionTransformer(nn.Module):
 
     def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=0, embed_dim=768,
                  depth=12, num_heads=12, mlp_ratio=4.0, qkv_bias=True, eps=1e-6, apply_head=False,
-                 compute_dtype="bf16", residual_dtype="auto", **_ignored):
+                 compute_dtype="bf16", residual_dtype="fp32", **_ignored):
         super().__init__()
         self.num_features = self.embed_dim = embed_dim
         self.apply_head = apply_head
         self.compute_dtype = _DT[compute_dtype]
-        # "auto": the stream follows the compute dtype (bf16 operands -> bf16 stream, the benchmarked mode since
-        # round 2; tests/test_training_curve_gpu.py bounds its loss curve against the fp32 oracle); "fp32" keeps it in fp32
+        # the residual stream between the blocks: "fp32" (default: the reference trains in fp32, and the fp32 stream ends a
+        # 50-step run within 0.06-0.08 % of the oracle loss, tests/test_training_curve_gpu.py), "bf16" (what bench.py times:
+        # 1.1-2.2 % on the same test), or "auto" = follow the compute dtype
         self.residual_dtype = self.compute_dtype if residual_dtype == "auto" else _DT[residual_dtype]
         self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)
         self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
@@ -132,7 +133,9 @@ class _EngineFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         eng = ctx.eng
+        held = eng.pack.begin_backward()        # .grad tensors that alias the flat buffer: accumulate, do not overwrite
         eng.backward(dout)
+        eng.pack.end_backward(held)
         grads = []
         for p, gv in zip(eng.pack.params, eng.pack.fresh_grad_views()):
             if not p.requires_grad:
