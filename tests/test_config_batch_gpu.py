@@ -1,0 +1,78 @@
+"""Model-level parity AT THE BATCH SIZES THE BASELINE CONFIGURATIONS RUN AT.
+
+Every other whole-model comparison runs at batch 2-8, where M = B*N is not a whole number of 256x256 GEMM tiles and the
+ragged 256x128 kernel runs: the launch forms bench.py times (persistent tile walk over 2.31 rounds, start stagger,
+k-sliced tails, paired split-K over K = 50 432, fused column sums, straight-line bf16 epilogues) only exist at batch 256.
+The records (tests/golden/gen_golden_full.py `config_batches`, micro-batched on the CPU):
+
+  oracle_dino_vitb16_bs256   C2, the headline: oracle (upstream DINO is absent), batch 256 at 224x224
+  oracle_dino_vitb8_96_bs128 C3: oracle, batch 128 at 96x96 (stored 28x28 pos grid resized to 12x12)
+  oracle_dino_vits16_32_bs128 C1: oracle, batch 128 at 32x32
+  full_cait_S24_224_bs256    C4: the REFERENCE's own cait_S24_224 class (models/cait.py:367-387), batch 256
+  full_swin_tiny_bs256       C5: the REFERENCE's own Swin-T (models/swin.py:823-844), DropPath 0, batch 256
+
+each holding logits [B,10], the mean-CE loss, every parameter's gradient norm and 256 sampled gradient entries per
+parameter.  The step that is compared is `bench.fixture_parity` — the same function bench.py's `parity` object comes
+from — in the fp32 parity mode (eager), in the benchmarked bf16 mode (bf16 residual stream; eager) and replayed from the
+HIP graph exactly as bench.py builds it (GraphedStep + FusedSGD, weight cast outside the capture).  Reference step:
+/root/reference/utils_network.py:406-453 at main.py's --bs.
+
+Tolerances = bench.PARITY_TOL (fp32: the north-star 1e-3 on logits, loss, gradient norms and sampled gradient entries;
+bf16: logits 2e-2, loss 1e-2, gradient norms 2.5e-2, cosine over each parameter's samples >= 0.999).  Measured values
+are printed."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+RECORDS = ["oracle_dino_vitb16_bs256", "oracle_dino_vitb8_96_bs128", "oracle_dino_vits16_32_bs128",
+           "full_cait_S24_224_bs256", "full_swin_tiny_bs256"]
+
+
+def _check(name, compute, residual, graph):
+    import bench
+    r = bench.fixture_parity(name, compute, residual, graph)
+    tol = bench.PARITY_TOL["fp32" if compute == "fp32" else "bf16"]
+    print(f"\n{name} [{compute} operands, {residual} stream, {'graph replay' if graph else 'eager'}]: {r}")
+    assert r["logits_rel"] <= tol["logits_rel"], r
+    assert r["loss_diff"] <= tol["loss_diff"], r
+    assert r["gradnorm_rel"] <= tol["gradnorm_rel"], r
+    assert r["gradsample_cos_min"] >= tol["grad_cos_min"], r
+    if compute == "fp32":
+        assert r["gradsample_rel"] <= 1e-3, r
+    return r
+
+
+@pytest.mark.parametrize("name", RECORDS)
+def test_fp32_mode_at_the_configuration_batch(name):
+    _check(name, "fp32", "fp32", False)
+
+
+@pytest.mark.parametrize("name", RECORDS)
+@pytest.mark.parametrize("residual", ["bf16", "fp32"])
+def test_bf16_mode_at_the_configuration_batch(name, residual):
+    r = _check(name, "bf16", residual, False)
+    if name == "oracle_dino_vitb16_bs256":
+        # the step that was just checked ran on the 256x256-tile kernel: every GEMM of the ViT-B/16 step at batch 256
+        # is whole 256x256x64 tiles (M = 50 432 = 197 x 256), and the library routes exactly those shapes to gemm_fast_kernel
+        from vit_torch_amd import ops
+        from vit_torch_amd._lib import EPI_BIAS_GELU, EPI_DGELU, EPI_RESIDUAL
+        assert r["gemm_flop_share_on_256x256_tiles"] > 0.999, r
+        M = 197 * 256
+        assert ops.gemm_uses_fast(M, 2304, 768) and ops.gemm_uses_fast(M, 3072, 768, epilogue=EPI_BIAS_GELU)
+        assert ops.gemm_uses_fast(M, 768, 3072, epilogue=EPI_RESIDUAL)
+        assert ops.gemm_uses_fast(M, 3072, 768, b_kmajor=False, epilogue=EPI_DGELU, colsum_part=True)
+        assert ops.gemm_pair_shares_a_launch(768, 768, 2304, 768, M)
+
+
+@pytest.mark.parametrize("name", RECORDS)
+def test_graph_replay_at_the_configuration_batch(name):
+    """The step as bench.py times it: GraphedStep(model, CrossEntropyLoss, FusedSGD(lr 1e-3, momentum 0.9)), one replay
+    from the record's weights."""
+    _check(name, "bf16", "bf16", True)

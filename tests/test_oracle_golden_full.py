@@ -138,3 +138,55 @@ def test_two_harness_sgd_steps_on_oracle_match_reference_classes(fam):
             want = float(rec[f"pnorm{s}/{n}"])
             assert abs(p.detach().double().norm().item() - want) <= 2e-6 * max(want, 1.0), (s, n)
     assert_close("head after 2 steps", m.head.weight, rec["head_after2"], 5e-6)
+
+
+@pytest.mark.parametrize("name,fam", [("full_swin_tiny_bs256", "swin"), ("full_cait_S24_224_bs256", "cait")])
+def test_oracle_matches_the_reference_class_records_at_batch_256(name, fam):
+    """Round 4's batch-256 records of the REFERENCE classes (tests/golden/gen_golden_full.py `config_batches`): the
+    seeded input regenerates bit-identically (checksum), and the oracle's per-sample logits of the first eight images
+    equal the record's (logits are per-sample: no need to run all 256 on the CPU here; loss and gradients at the full
+    batch are what the HIP path is held to on the GPU, tests/test_config_batch_gpu.py)."""
+    from oracle import cait_ref, swin_ref
+    from oracle.vit_ref import seeded_init_
+    top, groups = load(name)
+    B, S = int(top["batch"]), int(top["img"])
+    assert (B, S) == (256, 224) and tuple(top["logits"].shape) == (256, 10)
+    x, y = inputs(B, S, int(top["input_seed"]))
+    assert checksum(x) == pytest.approx(float(top["x_checksum"]), rel=1e-12)
+    assert torch.equal(y, top["labels"])
+    if fam == "swin":
+        ref = swin_ref.build("swin_tiny_patch4_window7_224", num_classes=10, drop_path_rate=0.0)
+        ref.head = nn.Linear(768, 10, bias=False)
+    else:
+        ref = cait_ref.build("cait_S24_224", num_classes=10)
+        ref.head = nn.Linear(384, 10, bias=False)
+    seeded_init_(ref, int(top["init_seed"]))
+    if "gamma" in top:
+        with torch.no_grad():
+            for n, p in ref.named_parameters():
+                if "gamma_" in n:
+                    p.fill_(float(top["gamma"]))
+    assert set(n for n, _ in ref.named_parameters()) == set(groups["gradnorm"]) == set(groups["gradsample"])
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        lo = ref(x[:8])
+    assert_close("logits[:8]", lo, top["logits"][:8], 5e-6)
+    # the record's loss is the mean CE of its own logits (micro-batched accumulation = the full-batch mean)
+    assert abs(F.cross_entropy(top["logits"], y).item() - float(top["loss"])) < 2e-6
+
+
+def test_headline_record_at_batch_256_is_self_consistent():
+    """oracle_dino_vitb16_bs256 (oracle-generated: upstream DINO is absent): input checksum, labels, and loss = mean CE of
+    the stored logits; the first two images' logits equal what the oracle gives on them alone."""
+    from oracle import vit_ref
+    top, groups = load("oracle_dino_vitb16_bs256")
+    x, y = inputs(256, 224, int(top["input_seed"]))
+    assert checksum(x) == pytest.approx(float(top["x_checksum"]), rel=1e-12)
+    assert torch.equal(y, top["labels"])
+    assert abs(F.cross_entropy(top["logits"], y).item() - float(top["loss"])) < 2e-6
+    m = vit_ref.build("dino_vitb16", classifier=10)
+    vit_ref.seeded_init_(m, int(top["init_seed"]))
+    with torch.no_grad():
+        lo = m(x[:2])
+    assert_close("logits[:2]", lo, top["logits"][:2], 5e-6)
+    assert len(groups["gradnorm"]) == len(list(m.named_parameters()))

@@ -245,6 +245,42 @@ def test_swin_drop_path_random_draws_have_the_right_rate():
     eng.saved = None
 
 
+def test_swin_step_with_active_drop_path_is_graph_capturable():
+    """the single-draw DropPath built its keep table with torch.tensor(list, device=...) inside
+    forward — a pageable-host copy + stream synchronise, illegal while a stream is capturing, so `bench.py --graph auto`
+    silently fell back to eager for Swin-T.  The table now lives on the device from the engine's construction: the step
+    with the configuration's DropPath rates captures, and every replay draws fresh masks (lr = 0: the weights stay put,
+    so a loss that changes between replays can only come from new masks)."""
+    from vit_torch_amd import CrossEntropyLoss, FusedSGD, GraphedStep
+    cfg = dict(TINY, drop_path_rate=0.5)
+    _, m = make_pair(cfg, "bf16", "bf16")
+    m.train()
+    g = torch.Generator("cpu").manual_seed(0)
+    x, y = torch.randn(16, 3, 56, 56, generator=g).cuda(), torch.randint(0, 10, (16,), generator=g).cuda()
+    crit = CrossEntropyLoss()
+    m.engine()
+    opt = FusedSGD(m.parameters(), lr=0.0, momentum=0.9)
+    gs = GraphedStep(m, crit, opt, x, y)                 # raises if anything in the step cannot be captured
+    losses = [float(gs(gs.x, gs.y).item()) for _ in range(6)]
+    assert all(l == l and abs(l) < 1e3 for l in losses), losses
+    assert len(set(losses)) > 1, f"six replays, one loss: the DropPath draw is frozen inside the graph ({losses})"
+
+
+def test_swin_graph_replay_equals_the_eager_step_at_rate_zero():
+    from vit_torch_amd import CrossEntropyLoss, FusedSGD, GraphedStep
+    _, m0 = make_pair(TINY, "bf16", "bf16")
+    m0.train()
+    g = torch.Generator("cpu").manual_seed(0)
+    x, y = torch.randn(16, 3, 56, 56, generator=g).cuda(), torch.randint(0, 10, (16,), generator=g).cuda()
+    m0.engine()
+    o0 = FusedSGD(m0.parameters(), lr=0.0, momentum=0.9)
+    with torch.no_grad():
+        eager = float(CrossEntropyLoss()(m0(x), y).item())
+    crit = CrossEntropyLoss()
+    gs0 = GraphedStep(m0, crit, o0, x, y)
+    assert float(gs0(gs0.x, gs0.y).item()) == pytest.approx(eager, rel=1e-6)
+
+
 def test_swin_t_full_size_fp32_logits_within_1e3():
     """BASELINE config 5 architecture (Swin-T, drop-path 0), batch 2, parity mode."""
     from oracle import swin_ref

@@ -320,3 +320,32 @@ def test_deferred_folds_leave_every_gradient_bit_identical(monkeypatch):
         grads.append({n: p.grad.clone() for n, p in m.named_parameters()})
     for n in grads[0]:
         assert torch.equal(grads[0][n], grads[1][n]), n
+
+
+# ------------------------------------------------------------- torch's accumulation contract ---
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+def test_second_backward_accumulates(compute):
+    """backward() twice without zero_grad(): .grad must hold the SUM (torch.autograd's contract).  The engine overwrites
+    its flat gradient buffer, and after the first backward every .grad IS a view of that buffer: round 3 silently returned
+    the second gradient alone.  Now the aliased spans are saved and added back (vitmi_axpy)."""
+    from vit_torch_amd import CrossEntropyLoss
+    _, m = make_pair(TINY, 10, compute)
+    crit = CrossEntropyLoss()
+    (xa, ya), (xb, yb) = data(6, 3, 32, 10, seed=3), data(6, 3, 32, 10, seed=4)
+    singles = []
+    for x, y in ((xa, ya), (xb, yb)):
+        m.zero_grad()                                   # set_to_none: a fresh gradient
+        crit(m(x.cuda()), y.cuda()).backward()
+        singles.append([p.grad.clone() for p in m.parameters()])
+    m.zero_grad()
+    crit(m(xa.cuda()), ya.cuda()).backward()
+    first_ptrs = [p.grad.data_ptr() for p in m.parameters()]
+    crit(m(xb.cuda()), yb.cuda()).backward()            # no zero_grad in between
+    for p, ptr, ga, gb in zip(m.parameters(), first_ptrs, *singles):
+        assert p.grad.data_ptr() == ptr                 # still the engine's buffer, accumulated in place
+        torch.testing.assert_close(p.grad, ga + gb, rtol=1e-6, atol=1e-7)
+    # zero_grad(set_to_none=False) keeps the aliasing .grad tensors, zeroed: the next backward is a plain gradient again
+    m.zero_grad(set_to_none=False)
+    crit(m(xb.cuda()), yb.cuda()).backward()
+    for p, gb in zip(m.parameters(), singles[1]):
+        torch.testing.assert_close(p.grad, gb, rtol=1e-6, atol=1e-7)

@@ -44,6 +44,11 @@ class GradReducer:
         self._pending_hi: Optional[int] = None
         self._works: List = []
         self.launched: List[tuple] = []      # (lo, hi) of every bucket, for tests
+        # bench.py's dp_proxy: with `timing` set, an event is recorded on the compute stream in front of every bucket's
+        # launch (the last one is kept) and another when finish() has joined them all: tail_ms() = what a step waits
+        # for between handing over its last bucket and being free to run the optimizer
+        self.timing = False
+        self._ev_last = self._ev_done = None
 
     # called by the engine when the gradients of `params` are final
     def section_ready(self, params) -> None:
@@ -68,6 +73,9 @@ class GradReducer:
         lo, hi = self._pending_lo, self._pending_hi
         self._pending_lo = self._pending_hi = None
         buf = self.pack.grad[lo:hi]
+        if self.timing:
+            self._ev_last = torch.cuda.Event(enable_timing=True)
+            self._ev_last.record()
         self.comm_active = True
         self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self.launched.append((lo, hi))
@@ -79,6 +87,16 @@ class GradReducer:
             w.wait()                      # the compute stream waits; kernels launched from here on run after the exchange
         self._works.clear()
         self.comm_active = False
+        if self.timing and self._ev_last is not None:
+            self._ev_done = torch.cuda.Event(enable_timing=True)
+            self._ev_done.record()
+
+    def tail_ms(self):
+        """Milliseconds between the last bucket's launch and finish() returning on the compute stream (timing mode)."""
+        if self._ev_last is None or self._ev_done is None:
+            return None
+        torch.cuda.synchronize()
+        return round(self._ev_last.elapsed_time(self._ev_done), 4)
 
     def launch_flags(self) -> int:
         """What the engine passes as `launch_flags` right now (vitmi.h VITMI_LAUNCH_*)."""

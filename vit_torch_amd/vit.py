@@ -169,6 +169,14 @@ def _head_layers(head) -> Optional[List[tuple]]:
     return None
 
 
+def _timing_events(eng):
+    """Two timing events for one launch of the instrumented step.  `eng.profile_external`: the step is being CAPTURED into a
+    HIP graph — `external` events become event-record nodes of the graph, so the per-launch durations are those of the
+    replayed graph (the launch form bench.py times), not of an eager step."""
+    ext = bool(getattr(eng, "profile_external", False))
+    return (torch.cuda.Event(enable_timing=True, external=ext), torch.cuda.Event(enable_timing=True, external=ext))
+
+
 def engine_gemm(eng, A, B, C, **k):
     """ops.gemm with the engine's implementation switch; when eng.profile is a list, each
     launch is bracketed by HIP events on the launch stream (bench.py's roofline leg)."""
@@ -183,7 +191,7 @@ def engine_gemm(eng, A, B, C, **k):
         return ops.gemm(A, B, C, impl=eng.gemm_impl, **k)
     akm, bkm = k.get("a_kmajor", True), k.get("b_kmajor", True)
     Kdim = A.shape[1] if akm else A.shape[0]
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0, e1 = _timing_events(eng)
     e0.record()
     ops.gemm(A, B, C, impl=eng.gemm_impl, **k)
     e1.record()
@@ -205,7 +213,7 @@ def engine_wgrad_pair(eng, dY0, X0, dW0, dY1, X1, dW1):
     if eng.profile is None:
         ops.gemm_pair(dY0, X0, dW0, dY1, X1, dW1, launch_flags=flags)
         return
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0, e1 = _timing_events(eng)
     e0.record()
     ops.gemm_pair(dY0, X0, dW0, dY1, X1, dW1, launch_flags=flags)
     e1.record()
@@ -221,7 +229,7 @@ def dgelu_gemm_with_bias_grad(eng, Gb, W2, dH, pre, bias_grad):
     pass (callers may run it on a side stream)."""
     M, Dh = dH.shape
     K = Gb.shape[1]
-    fused = (dH.dtype == torch.bfloat16 and eng.gemm_impl == GEMM_AUTO and eng.profile is None
+    fused = (dH.dtype == torch.bfloat16 and eng.gemm_impl == GEMM_AUTO
              and ops.gemm_uses_fast(M, Dh, K, b_kmajor=False, epilogue=EPI_DGELU, colsum_part=True))
     if fused:
         part = torch.empty(((M + 127) // 128, Dh), dtype=torch.float32, device=dH.device)
