@@ -40,6 +40,7 @@ struct GemmArgs {
   // tiles [0, tiles1) belong to this problem, [tiles1, tiles1 + tiles2) to the second one (tiles1 == 0: no pair)
   const void* A2; const void* B2; int64_t lda2, ldb2, M2, N2; int tiles1, tiles_n2; float* ws2;
   int stag_cycles, stag_phases;   // gemm_fast, persistent walk: start delay of the workgroups with the shorter tile list
+  int dbg_alias;                  // gemm_fast diagnostic: bit 0 = every tile stages A panel 0, bit 1 = B panel 0 (operand streams out of L2: tools/r04_gemm_probe.py)
   int side_depth;                 // gemm_fast, bf16 epilogues with a side input: strips of it in flight (1 = round 2's one ahead, 3)
   EpiArgs e;
 };

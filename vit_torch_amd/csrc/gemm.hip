@@ -20,6 +20,10 @@ static std::atomic<int> g_gemm_strict_wait{0};
 extern "C" void vitmi_debug_gemm_strict_wait(int on) { g_gemm_strict_wait = on != 0; }
 static std::atomic<unsigned long long*> g_gemm_dbg{nullptr};
 static std::atomic<int> g_gemm_dbg_blocks{64};
+static std::atomic<int> g_gemm_alias{0};
+// diagnostic hook (tools/r04_gemm_probe.py): every tile of the 256x256 kernel stages operand panel 0 (bit 0: A, bit 1: B) —
+// WRONG results on purpose; it takes the streamed operand's HBM / Infinity-Cache misses out of the main loop
+extern "C" void vitmi_debug_gemm_alias(int bits) { g_gemm_alias = bits; }
 extern "C" void vitmi_debug_gemm_stamps(unsigned long long* buf) { g_gemm_dbg = buf; g_gemm_dbg_blocks = 64; }
 // timeline of the first `blocks` workgroups: buf holds 64 + 4 * blocks entries
 extern "C" void vitmi_debug_gemm_timeline(unsigned long long* buf, int blocks) { g_gemm_dbg = buf; g_gemm_dbg_blocks = blocks; }
@@ -292,6 +296,7 @@ static int build_args(const vitmi_gemm_desc* d, GemmArgs* out) {
   g.A2 = g.B2 = nullptr; g.lda2 = g.ldb2 = g.M2 = g.N2 = 0; g.tiles1 = g.tiles_n2 = 0; g.ws2 = nullptr;
   g.dbg = g_gemm_dbg;
   g.dbg_blocks = g_gemm_dbg_blocks;
+  g.dbg_alias = g_gemm_alias;
   g.batch = d->batch > 1 ? d->batch : 1;
   g.batch_inner = d->batch_inner > 0 ? d->batch_inner : 1;
   for (int i = 0; i < 2; ++i) { g.a_bs[i] = d->a_bs[i]; g.b_bs[i] = d->b_bs[i]; g.c_bs[i] = d->c_bs[i]; }
@@ -438,6 +443,7 @@ void vitmi_debug_reset_gemm() {
   g_gemm_strict_wait = 0;
   g_gemm_dbg = nullptr;
   g_gemm_dbg_blocks = 64;
+  g_gemm_alias = 0;
   g_skinny = 1;
   g_c_policy = -1;
   g_nt_min_mb = 64;

@@ -500,6 +500,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
   // epilogue (glds16_hidden)
   auto start_tile = [&](int64_t m0, int64_t n0, auto hid) {
     constexpr bool HID = decltype(hid)::value || PIPE != 0;     // the phased loops wait and order every DMA themselves: all of theirs go out unseen
+    if (g.dbg_alias & 1) m0 = 0;                                // diagnostic (vitmi_debug_gemm_alias): operand panel 0 for every tile
+    if (g.dbg_alias & 2) n0 = 0;
     if constexpr (RINGP) {
       sa.init(A, lda, m0, kb0, wave, lane);
       sb.init(B, ldb, n0, kb0, wave, lane);
