@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VITMI_VERSION 107
+#define VITMI_VERSION 108
 
 enum { VITMI_F32 = 0, VITMI_BF16 = 1 };
 
@@ -244,6 +244,22 @@ int vitmi_th_softmax_bwd(const void* S, const void* P, const void* dPm, const fl
                          const float* Ww, void* dS, float* dWl, float* dbl, float* dWw, float* dbw,
                          int dtype, int64_t B, int64_t H, int64_t N, int64_t Nk, int64_t ld,
                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* Talking-heads attention as ONE op (ABI 108; models/cait.py:111-128): O = proj_w(softmax(proj_l(scale q k^T))) v with the
+ * score rows resident in LDS and both head mixes on the matrix pipe; the forward keeps nothing but O.  bf16, H = 8,
+ * hd = 48, N <= 224, N % 4 == 0 (vitmi_th_attn_supported); other shapes / fp32 take the three-call form above.
+ * qkv [B,N,3,H,hd], out / dout [B,N,H,hd].  The backward recomputes the scores, writes dQ into the q slots of dqkv, the
+ * four proj_l / proj_w gradients (fp32, overwritten), and hands dS and Pm = P' ([B,H,N,ld] bf16) to the caller's two
+ * remaining batched products (dK = scale dS^T q, dV = Pm^T dout).  workspace: vitmi_th_attn_workspace bytes, 256-B aligned. */
+int vitmi_th_attn_supported(int dtype, int64_t H, int64_t N, int64_t hd);
+size_t vitmi_th_attn_workspace(int64_t B, int64_t H, int64_t N, int64_t hd);
+int vitmi_th_attn_fwd(const void* qkv, const float* Wl, const float* bl, const float* Ww, const float* bw,
+                      void* out, int dtype, int64_t B, int64_t H, int64_t N, int64_t hd, float scale,
+                      void* workspace, size_t workspace_bytes, void* stream);
+int vitmi_th_attn_bwd(const void* qkv, const void* dout, const float* Wl, const float* bl, const float* Ww,
+                      const float* bw, void* dqkv, void* dS, void* Pm, int64_t ld, float* dWl, float* dbl,
+                      float* dWw, float* dbw, int dtype, int64_t B, int64_t H, int64_t N, int64_t hd, float scale,
+                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* Class attention core (models/cait.py:44-52): one query per image (the projected CLS
  * token, q [B, H*hd]) against k/v rows [B, N, .] with token stride kv_token_stride

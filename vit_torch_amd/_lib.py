@@ -93,6 +93,11 @@ SIGNATURES = {
     "vitmi_th_softmax_bwd_workspace": (c_sz, [c_i64, c_i64, c_i64]),
     "vitmi_th_softmax_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int,
                                        c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_sz, c_vp]),
+    "vitmi_th_attn_supported": (C.c_int, [C.c_int, c_i64, c_i64, c_i64]),
+    "vitmi_th_attn_workspace": (c_sz, [c_i64, c_i64, c_i64, c_i64]),
+    "vitmi_th_attn_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_i64, c_f32, c_vp, c_sz, c_vp]),
+    "vitmi_th_attn_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, C.c_int,
+                                    c_i64, c_i64, c_i64, c_i64, c_f32, c_vp, c_sz, c_vp]),
     "vitmi_class_attn_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_i64, c_f32, c_vp]),
     "vitmi_class_attn_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int,
                                        c_i64, c_i64, c_i64, c_i64, c_f32, c_vp]),

@@ -34,6 +34,7 @@ SOURCES = [
     "attention.hip",
     "attention_f32.hip",
     "cait_ops.hip",
+    "cait_fused.hip",
     "swin_ops.hip",
 ]
 HEADERS = ["common.h", "epilogue.h", "gemm_tile.h", "../../include/vitmi.h"]

@@ -170,6 +170,8 @@ class CaitEngine:
         if dev.type != "cuda":
             raise VitmiError("move the model to the GPU before the first forward")
         self.T, self.R = model.compute_dtype, model.residual_dtype
+        # talking-heads attention as one fused op where the shape allows (VITMI_TH_FUSED=0: the three-call form, for A/B)
+        self.fused_th = os.environ.get("VITMI_TH_FUSED", "1") != "0"
         if self.T == torch.float32 and self.R != torch.float32:
             raise VitmiError("fp32 compute needs an fp32 residual stream")
         self.head = _head_layers(model.head)
@@ -245,6 +247,7 @@ class CaitEngine:
                    bias=pk.f32(conv.bias) if conv.bias is not None else None,
                    pos=pk.f32(m.pos_embed).view(Np, D), n_tok=Np)
         trunk = []
+        fused_th = self.fused_th and T == torch.bfloat16 and ops.th_attn_supported(T, H, Np, hd)
         for blk in m.blocks:
             a, mlp = blk.attn, blk.mlp
             ln1, mean1, rstd1 = new(M, D, T), vec(M), vec(M)
@@ -252,16 +255,23 @@ class CaitEngine:
                               blk.norm1.eps, M=M, D=D)
             qkv = new(M, 3 * D, T)
             self._gemm(ln1, self._w(a.qkv.weight), qkv, bias=pk.f32(a.qkv.bias) if a.qkv.bias is not None else None)
-            S = torch.empty((B, H, Np, NS), dtype=T, device=dev)
-            self._scores(qkv, S, B, Np, H, hd, NS, a.scale)
-            P, Pm = torch.empty_like(S), torch.empty_like(S)
-            ops.th_softmax_fwd(S, pk.f32(a.proj_l.weight), pk.f32(a.proj_l.bias), pk.f32(a.proj_w.weight),
-                               pk.f32(a.proj_w.bias), P, Pm, B, H, Np, Np, NS)
             O = new(M, D, T)
             D3 = 3 * D
-            ops.gemm_batched(Pm, qkv, O, M=Np, N=hd, K=Np, lda=NS, ldb=D3, ldc=D, a_kmajor=True, b_kmajor=False,
-                             batch=B * H, batch_inner=H, a_bs=(H * Np * NS, Np * NS), b_bs=(Np * D3, hd),
-                             c_bs=(Np * D, hd), b_off=2 * D)
+            if fused_th:
+                # ONE op: the score rows stay in LDS, both head mixes run on the matrix pipe, nothing but O is kept
+                # (cait_fused.hip; the backward recomputes the scores from q, k)
+                ops.th_attn_fwd(qkv, pk.f32(a.proj_l.weight), pk.f32(a.proj_l.bias), pk.f32(a.proj_w.weight),
+                                pk.f32(a.proj_w.bias), O, B, H, Np, hd, a.scale)
+                S = P = Pm = None
+            else:
+                S = torch.empty((B, H, Np, NS), dtype=T, device=dev)
+                self._scores(qkv, S, B, Np, H, hd, NS, a.scale)
+                P, Pm = torch.empty_like(S), torch.empty_like(S)
+                ops.th_softmax_fwd(S, pk.f32(a.proj_l.weight), pk.f32(a.proj_l.bias), pk.f32(a.proj_w.weight),
+                                   pk.f32(a.proj_w.bias), P, Pm, B, H, Np, Np, NS)
+                ops.gemm_batched(Pm, qkv, O, M=Np, N=hd, K=Np, lda=NS, ldb=D3, ldc=D, a_kmajor=True, b_kmajor=False,
+                                 batch=B * H, batch_inner=H, a_bs=(H * Np * NS, Np * NS), b_bs=(Np * D3, hd),
+                                 c_bs=(Np * D, hd), b_off=2 * D)
             X1, f1 = new(M, D, R), new(M, D, T)
             self._gemm(O, self._w(a.proj.weight), X1, epilogue=EPI_RESIDUAL, bias=pk.f32(a.proj.bias), R=X,
                        gamma=pk.f32(blk.gamma_1), C2=f1)
@@ -474,20 +484,30 @@ class CaitEngine:
             self._gemm(Gb, O, pk.g(a.proj.weight), a_kmajor=False, b_kmajor=False)
             # talking-heads attention backward
             dqkv = new(M, D3, T)
-            dPm = torch.empty_like(S)
-            ops.gemm_batched(dO, qkv, dPm, M=Np, N=Np, K=hd, lda=D, ldb=D3, ldc=NS, a_kmajor=True, b_kmajor=True,
-                             batch=B * H, batch_inner=H, a_bs=(Np * D, hd), b_bs=(Np * D3, hd),
-                             c_bs=(H * Np * NS, Np * NS), b_off=2 * D)
+            if S is None:
+                # fused form: the scores are recomputed inside the kernel, which also forms dP' = dO v^T, runs the softmax
+                # backward through both mixes, writes dQ and the four mixing-parameter gradients, and leaves dS and P' for
+                # the two products whose contraction runs over the QUERIES
+                dS = torch.empty((B, H, Np, NS), dtype=T, device=dev)
+                Pm = torch.empty((B, H, Np, NS), dtype=T, device=dev)
+                ops.th_attn_bwd(qkv, dO, pk.f32(a.proj_l.weight), pk.f32(a.proj_l.bias), pk.f32(a.proj_w.weight),
+                                pk.f32(a.proj_w.bias), dqkv, dS, Pm, NS, pk.g(a.proj_l.weight), pk.g(a.proj_l.bias),
+                                pk.g(a.proj_w.weight), pk.g(a.proj_w.bias), B, H, Np, hd, a.scale)
+            else:
+                dPm = torch.empty_like(S)
+                ops.gemm_batched(dO, qkv, dPm, M=Np, N=Np, K=hd, lda=D, ldb=D3, ldc=NS, a_kmajor=True, b_kmajor=True,
+                                 batch=B * H, batch_inner=H, a_bs=(Np * D, hd), b_bs=(Np * D3, hd),
+                                 c_bs=(H * Np * NS, Np * NS), b_off=2 * D)
+                dS = torch.empty_like(S)
+                ops.th_softmax_bwd(S, P, dPm, pk.f32(a.proj_l.weight), pk.f32(a.proj_w.weight), dS,
+                                   pk.g(a.proj_l.weight), pk.g(a.proj_l.bias), pk.g(a.proj_w.weight),
+                                   pk.g(a.proj_w.bias), B, H, Np, Np, NS)
+                ops.gemm_batched(dS, qkv, dqkv, M=Np, N=hd, K=Np, lda=NS, ldb=D3, ldc=D3, a_kmajor=True, b_kmajor=False,
+                                 batch=B * H, batch_inner=H, a_bs=(H * Np * NS, Np * NS), b_bs=(Np * D3, hd),
+                                 c_bs=(Np * D3, hd), b_off=D, alpha=a.scale)                          # dQ = scale dS K
             ops.gemm_batched(Pm, dO, dqkv, M=Np, N=hd, K=Np, lda=NS, ldb=D, ldc=D3, a_kmajor=False, b_kmajor=False,
                              batch=B * H, batch_inner=H, a_bs=(H * Np * NS, Np * NS), b_bs=(Np * D, hd),
-                             c_bs=(Np * D3, hd), c_off=2 * D)                                   # dV
-            dS = torch.empty_like(S)
-            ops.th_softmax_bwd(S, P, dPm, pk.f32(a.proj_l.weight), pk.f32(a.proj_w.weight), dS,
-                               pk.g(a.proj_l.weight), pk.g(a.proj_l.bias), pk.g(a.proj_w.weight),
-                               pk.g(a.proj_w.bias), B, H, Np, Np, NS)
-            ops.gemm_batched(dS, qkv, dqkv, M=Np, N=hd, K=Np, lda=NS, ldb=D3, ldc=D3, a_kmajor=True, b_kmajor=False,
-                             batch=B * H, batch_inner=H, a_bs=(H * Np * NS, Np * NS), b_bs=(Np * D3, hd),
-                             c_bs=(Np * D3, hd), b_off=D, alpha=a.scale)                          # dQ = scale dS K
+                             c_bs=(Np * D3, hd), c_off=2 * D)                                   # dV = P'^T dO
             ops.gemm_batched(dS, qkv, dqkv, M=Np, N=hd, K=Np, lda=NS, ldb=D3, ldc=D3, a_kmajor=False, b_kmajor=False,
                              batch=B * H, batch_inner=H, a_bs=(H * Np * NS, Np * NS), b_bs=(Np * D3, hd),
                              c_bs=(Np * D3, hd), c_off=D, alpha=a.scale)                          # dK = scale dS^T Q

@@ -56,6 +56,7 @@ int vitmi_cu_count() {
 static std::atomic<int> g_persist_override{-1};
 void vitmi_debug_reset_attention();
 void vitmi_debug_reset_cait();
+void vitmi_debug_reset_cait_fused();
 void vitmi_debug_reset_gemm();
 void vitmi_debug_reset_gemm_fast();
 void vitmi_debug_reset_gemm_fast2();
@@ -69,6 +70,7 @@ extern "C" void vitmi_debug_reset(void) {
   g_persist_override.store(-1, std::memory_order_relaxed);
   vitmi_debug_reset_attention();
   vitmi_debug_reset_cait();
+  vitmi_debug_reset_cait_fused();
   vitmi_debug_reset_gemm();
   vitmi_debug_reset_gemm_fast();
   vitmi_debug_reset_gemm_fast2();

@@ -470,6 +470,38 @@ def th_softmax_bwd(S, P, dPm, Wl, Ww, dS, dWl, dbl, dWw, dbw, B, H, N, Nk, ld):
           "vitmi_th_softmax_bwd")
 
 
+def th_attn_supported(t, H, N, hd) -> bool:
+    """Host-only query: do the fused talking-heads kernels take this shape / dtype?"""
+    code = (BF16 if t == torch.bfloat16 else F32 if t == torch.float32 else -1) if isinstance(t, torch.dtype) else dtype_code(t)
+    return bool(load().vitmi_th_attn_supported(code, H, N, hd))
+
+
+def _th_ws(B, H, N, hd, device):
+    w = workspace(load().vitmi_th_attn_workspace(B, H, N, hd) + 256, device)
+    off = (-w.data_ptr()) % 256
+    return w.data_ptr() + off, w.numel() - off
+
+
+def th_attn_fwd(qkv, Wl, bl, Ww, bw, out, B, H, N, hd, scale):
+    """out [B,N,H,hd] = talking-heads attention of qkv [B,N,3,H,hd] (vitmi_th_attn_fwd: scores never leave the CU)."""
+    _need_cuda(qkv, out)
+    assert qkv.is_contiguous() and out.is_contiguous()
+    ptr, nb = _th_ws(B, H, N, hd, qkv.device)
+    check(load().vitmi_th_attn_fwd(qkv.data_ptr(), Wl.data_ptr(), bl.data_ptr(), Ww.data_ptr(), bw.data_ptr(), out.data_ptr(),
+                                   dtype_code(qkv), B, H, N, hd, float(scale), ptr, nb, _stream()), "vitmi_th_attn_fwd")
+    return out
+
+
+def th_attn_bwd(qkv, dout, Wl, bl, Ww, bw, dqkv, dS, Pm, ld, dWl, dbl, dWw, dbw, B, H, N, hd, scale):
+    """dQ into dqkv's q slots, dS and Pm ([B,H,N,ld]) for the caller's dK / dV products, the four mixing-parameter gradients."""
+    _need_cuda(qkv, dout, dqkv, dS, Pm)
+    assert qkv.is_contiguous() and dout.is_contiguous() and dqkv.is_contiguous() and dS.is_contiguous() and Pm.is_contiguous()
+    ptr, nb = _th_ws(B, H, N, hd, qkv.device)
+    check(load().vitmi_th_attn_bwd(qkv.data_ptr(), dout.data_ptr(), Wl.data_ptr(), bl.data_ptr(), Ww.data_ptr(), bw.data_ptr(),
+                                   dqkv.data_ptr(), dS.data_ptr(), Pm.data_ptr(), ld, dWl.data_ptr(), dbl.data_ptr(), dWw.data_ptr(),
+                                   dbw.data_ptr(), dtype_code(qkv), B, H, N, hd, float(scale), ptr, nb, _stream()), "vitmi_th_attn_bwd")
+
+
 def class_attn_fwd(q, k, v, kv_stride, out, p_save, B, H, N, hd, scale):
     _need_cuda(q, k, v, out, p_save)
     check(load().vitmi_class_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), kv_stride, out.data_ptr(),
