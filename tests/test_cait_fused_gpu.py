@@ -39,7 +39,7 @@ def make(B, N, seed=0, H=8, hd=48):
 
 def fused(ops, qkv, dO, Wl, bl, Ww, bw, scale):
     B, N, _, H, hd = qkv.shape
-    D, D3, NS = H * hd, 3 * H * hd, (N + 7) // 8 * 8
+    D, D3, NS = H * hd, 3 * H * hd, 224
     dev = "cuda"
     q, do = qkv.cuda().contiguous(), dO.cuda().contiguous()
     W = [t.cuda().contiguous() for t in (Wl, bl, Ww, bw)]

@@ -6,7 +6,7 @@ from vit_torch_amd import ops  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 N, H, hd = 196, 8, 48
-D, D3, NS = H * hd, 3 * H * hd, 200
+D, D3, NS = H * hd, 3 * H * hd, 224
 bt = torch.bfloat16
 dev = "cuda"
 qkv = (torch.randn(B * N, D3, device=dev) * 0.7).to(bt)
@@ -73,13 +73,14 @@ import ctypes, numpy as np
 from vit_torch_amd import _lib
 raw = ctypes.CDLL(str(_lib.LIB_PATH))
 raw.vitmi_debug_th_attn_stamps.argtypes = [ctypes.c_void_p]
-for name, f, nwg in (("forward", fwdf, B * 7), ("backward", bwdf_k, B * 13)):
+for name, f, nwg, cols in (("forward", fwdf, B, [1, 2, 3, 4, 5, 6]), ("backward", bwdf_k, 8 * ((B + 7) // 8) * 13, [1, 2, 3, 4, 5, 7])):
     buf = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
     raw.vitmi_debug_th_attn_stamps(buf.data_ptr())
     f()
     torch.cuda.synchronize()
     raw.vitmi_debug_th_attn_stamps(None)
     t = buf.cpu().numpy().reshape(nwg, 8).astype(np.float64)
-    mid = t[nwg // 3: 2 * nwg // 3]
-    d = np.diff(mid[:, :6], axis=1)
-    print(f"  {name} phase cycles (median of mid-launch workgroups): " + "  ".join(f"{x:.0f}" for x in np.median(d, axis=0)) + f"   total {np.median(mid[:, 5] - mid[:, 0]):.0f}")
+    t = t[nwg // 3: 2 * nwg // 3]
+    d = np.diff(t[:, cols], axis=1)
+    print(f"  {name}, first block of a workgroup, cycles (S | wait | R | wait | last phase): " + "  ".join(f"{x:.0f}" for x in np.median(d, axis=0))
+          + f"   whole workgroup {np.median(t[:, 7] - t[:, 0]):.0f}")

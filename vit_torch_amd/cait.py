@@ -488,10 +488,11 @@ class CaitEngine:
                 # fused form: the scores are recomputed inside the kernel, which also forms dP' = dO v^T, runs the softmax
                 # backward through both mixes, writes dQ and the four mixing-parameter gradients, and leaves dS and P' for
                 # the two products whose contraction runs over the QUERIES
-                dS = torch.empty((B, H, Np, NS), dtype=T, device=dev)
-                Pm = torch.empty((B, H, Np, NS), dtype=T, device=dev)
+                NSb = 224                # the kernel writes all 224 key slots of a score row (no per-tile store branches)
+                dS = torch.empty((B, H, Np, NSb), dtype=T, device=dev)
+                Pm = torch.empty((B, H, Np, NSb), dtype=T, device=dev)
                 ops.th_attn_bwd(qkv, dO, pk.f32(a.proj_l.weight), pk.f32(a.proj_l.bias), pk.f32(a.proj_w.weight),
-                                pk.f32(a.proj_w.bias), dqkv, dS, Pm, NS, pk.g(a.proj_l.weight), pk.g(a.proj_l.bias),
+                                pk.f32(a.proj_w.bias), dqkv, dS, Pm, NSb, pk.g(a.proj_l.weight), pk.g(a.proj_l.bias),
                                 pk.g(a.proj_w.weight), pk.g(a.proj_w.bias), B, H, Np, hd, a.scale)
             else:
                 dPm = torch.empty_like(S)
@@ -505,11 +506,12 @@ class CaitEngine:
                 ops.gemm_batched(dS, qkv, dqkv, M=Np, N=hd, K=Np, lda=NS, ldb=D3, ldc=D3, a_kmajor=True, b_kmajor=False,
                                  batch=B * H, batch_inner=H, a_bs=(H * Np * NS, Np * NS), b_bs=(Np * D3, hd),
                                  c_bs=(Np * D3, hd), b_off=D, alpha=a.scale)                          # dQ = scale dS K
-            ops.gemm_batched(Pm, dO, dqkv, M=Np, N=hd, K=Np, lda=NS, ldb=D, ldc=D3, a_kmajor=False, b_kmajor=False,
-                             batch=B * H, batch_inner=H, a_bs=(H * Np * NS, Np * NS), b_bs=(Np * D, hd),
+            NSd = dS.shape[-1]
+            ops.gemm_batched(Pm, dO, dqkv, M=Np, N=hd, K=Np, lda=NSd, ldb=D, ldc=D3, a_kmajor=False, b_kmajor=False,
+                             batch=B * H, batch_inner=H, a_bs=(H * Np * NSd, Np * NSd), b_bs=(Np * D, hd),
                              c_bs=(Np * D3, hd), c_off=2 * D)                                   # dV = P'^T dO
-            ops.gemm_batched(dS, qkv, dqkv, M=Np, N=hd, K=Np, lda=NS, ldb=D3, ldc=D3, a_kmajor=False, b_kmajor=False,
-                             batch=B * H, batch_inner=H, a_bs=(H * Np * NS, Np * NS), b_bs=(Np * D3, hd),
+            ops.gemm_batched(dS, qkv, dqkv, M=Np, N=hd, K=Np, lda=NSd, ldb=D3, ldc=D3, a_kmajor=False, b_kmajor=False,
+                             batch=B * H, batch_inner=H, a_bs=(H * Np * NSd, Np * NSd), b_bs=(Np * D3, hd),
                              c_bs=(Np * D3, hd), c_off=D, alpha=a.scale)                          # dK = scale dS^T Q
             dln1 = new(M, D, T)
             self._gemm(dqkv, self._w(a.qkv.weight), dln1, b_kmajor=False)

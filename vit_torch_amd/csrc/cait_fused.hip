@@ -31,6 +31,7 @@
 // (matrix pipe, planes as both operands), writes dQ, and hands dS and P' to HBM for the two remaining batched
 // products (dK = scale dS^T q, dV = P'^T dO).
 #include <atomic>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -47,7 +48,13 @@ __device__ __forceinline__ unsigned long long th_stamp() {
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
   return t;
 }
+// phase stamps: compiled in only with -DVITMI_TH_STAMPS (tools/th_attn_bench.py's breakdown); as a run-time option every
+// stamp was a branch on the buffer pointer around the phase boundaries of the production kernels
+#ifdef VITMI_TH_STAMPS
 #define TH_STAMP(k) do { if (dbg && threadIdx.x == 0) dbg[(int64_t)blockIdx.x * 8 + (k)] = th_stamp(); } while (0)
+#else
+#define TH_STAMP(k) do { } while (0)
+#endif
 __device__ __forceinline__ bf16x4 tr4(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, p));
 }
@@ -76,14 +83,23 @@ __device__ __forceinline__ bf16x8 zero8() {
 // mix runs through W^T (backward).
 __device__ __forceinline__ bf16x8 mix_operand(const float* __restrict__ W, bool transpose, int lane) {
   const int n = lane & 15, kq = lane >> 4;
+  // every lane loads its eight weights unconditionally and selects arithmetically: with the selection as a condition hipcc
+  // guarded each load with its own exec-mask branch and vmcnt(0) — 32 serialized round trips at the top of the kernel
+  float w[8];
+  if (!transpose) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(W + (n & 7) * TNH), b = *reinterpret_cast<const f32x4*>(W + (n & 7) * TNH + 4);
+    w[0] = a[0]; w[1] = a[1]; w[2] = a[2]; w[3] = a[3]; w[4] = b[0]; w[5] = b[1]; w[6] = b[2]; w[7] = b[3];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) w[e] = W[e * TNH + (n & 7)];
+  }
+  const bool mine = (kq & 1) == (n >> 3);
+  const float s_hi = (mine && kq < 2) ? 1.f : 0.f, s_lo = (mine && kq >= 2) ? 1.f : 0.f;
   bf16x8 r;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const float w = transpose ? W[e * TNH + (n & 7)] : W[(n & 7) * TNH + e];
-    const bf16 hi = (bf16)w;
-    const float lo = w - (float)hi;
-    const float v = ((kq & 1) == (n >> 3)) ? (kq < 2 ? (float)hi : lo) : 0.f;
-    r[e] = (bf16)v;
+    const float hi = (float)(bf16)w[e];
+    r[e] = (bf16)(s_hi * hi + s_lo * (w[e] - hi));
   }
   return r;
 }
@@ -161,13 +177,19 @@ __device__ __forceinline__ void softmax_row(f32x4 (&d)[7], float bias, int N, in
   const int p0 = 16 * (n >> 3) + 4 * pq;
   float m = -INFINITY;
 #pragma unroll
-  for (int t = 0; t < 7; ++t)
+  for (int t = 0; t < 7; ++t) {
+    if (32 * t + 32 <= N) {                    // wave-uniform: a whole tile of valid positions needs no per-position mask (as
+#pragma unroll                                  // 28 hoisted compare results the masks cost 56 SGPRs and spilled)
+      for (int r = 0; r < 4; ++r) { d[t][r] += bias; m = fmaxf(m, d[t][r]); }
+    } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float s = (32 * t + p0 + r < N) ? d[t][r] + bias : -INFINITY;
-      d[t][r] = s;
-      m = fmaxf(m, s);
+      for (int r = 0; r < 4; ++r) {
+        const float s = (32 * t + p0 + r < N) ? d[t][r] + bias : -INFINITY;
+        d[t][r] = s;
+        m = fmaxf(m, s);
+      }
     }
+  }
   m = head_max(m);
   float l = 0.f;
 #pragma unroll
@@ -225,17 +247,10 @@ __global__ __launch_bounds__(256) void th_pack_kernel(const bf16* __restrict__ q
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int n = lane & 15, kq = lane >> 4;
-  if (!BWD) {                                                       // forward: K as 16 x 16 x 16 fragments (no d padding)
-    for (int f = wv; f < RF16_FRAGS; f += 4) {
-      const int kbk = f / 3, ks = f % 3;
-      *reinterpret_cast<bf16x4*>(rfK + ((int64_t)bh * RF16_FRAGS + f) * 512 + lane * 8) = *reinterpret_cast<const bf16x4*>(&Kt[16 * kbk + n][16 * ks + 4 * kq]);
-    }
-  }
-  for (int f = wv; BWD && f < RF_FRAGS; f += 4) {                   // backward, rows-type: K and V
-    const int kbk = f >> 1, ks = f & 1;
-    const int d0 = min(32 * ks + 8 * kq, PK_LD - 8);                // d 48..55 of the staged rows are zero
-    *reinterpret_cast<bf16x8*>(rfK + ((int64_t)bh * RF_FRAGS + f) * 1024 + lane * 16) = *reinterpret_cast<const bf16x8*>(&Kt[16 * kbk + n][d0]);
-    if (BWD) *reinterpret_cast<bf16x8*>(rfV + ((int64_t)bh * RF_FRAGS + f) * 1024 + lane * 16) = *reinterpret_cast<const bf16x8*>(&Vt[16 * kbk + n][d0]);
+  for (int f = wv; f < RF16_FRAGS; f += 4) {                        // rows-type: K (and V for the backward)
+    const int kbk = f / 3, ks = f % 3;
+    *reinterpret_cast<bf16x4*>(rfK + ((int64_t)bh * RF16_FRAGS + f) * 512 + lane * 8) = *reinterpret_cast<const bf16x4*>(&Kt[16 * kbk + n][16 * ks + 4 * kq]);
+    if (BWD) *reinterpret_cast<bf16x4*>(rfV + ((int64_t)bh * RF16_FRAGS + f) * 512 + lane * 8) = *reinterpret_cast<const bf16x4*>(&Vt[16 * kbk + n][16 * ks + 4 * kq]);
   }
   for (int f = wv; f < TF_FRAGS; f += 4) {                          // T-type: V (forward) / K (backward)
     const int db = f / 7, ks = f % 7;
@@ -244,6 +259,21 @@ __global__ __launch_bounds__(256) void th_pack_kernel(const bf16* __restrict__ q
     for (int e = 0; e < 8; ++e) v[e] = BWD ? Kt[32 * ks + 8 * kq + e][16 * db + n] : Vt[32 * ks + 8 * kq + e][16 * db + n];
     *reinterpret_cast<bf16x8*>(tf + ((int64_t)bh * TF_FRAGS + f) * 1024 + lane * 16) = v;
   }
+}
+
+// Fragment load at wave-uniform base + 32-bit lane offset.  The offset is made opaque per load: given the constant part,
+// hipcc materialised a 64-bit per-lane address for every one of the ~100 fragment offsets of the backward kernel and
+// hoisted them out of the block loop — 210 registers of addresses, 238 dwords of scratch.  One v_add per load instead.
+template <typename T> __device__ __forceinline__ T ldg_u(const char* ubase, unsigned lane_off, unsigned const_off) {
+  asm volatile("" : "+v"(lane_off));                                // the constant is added BEHIND the opaque point: not loop-invariant
+  return *reinterpret_cast<const T*>(ubase + (lane_off + const_off));
+}
+// ... with a wave-uniform run-time offset as well (the rotated fragment order): opaque too, or each of the ~50 rotated bases
+// becomes a hoisted SGPR pair
+template <typename T> __device__ __forceinline__ T ldg_uu(const char* ubase, int uoff, unsigned lane_off, unsigned const_off) {
+  asm volatile("" : "+s"(uoff));
+  asm volatile("" : "+v"(lane_off));
+  return *reinterpret_cast<const T*>(ubase + uoff + (lane_off + const_off));
 }
 
 // d-slot fragment of a 16-row operand block with hd = 48 padded to 64: k-step ks, octet kq -> d = 32 ks + 8 kq (zero beyond 48)
@@ -305,11 +335,11 @@ __global__ __launch_bounds__(512) void th_attn_fwd_kernel(const bf16* __restrict
   load_q(qb0, qf);
   const bf16x8 wl = mix_operand(Wl, false, lane), ww = mix_operand(Ww, false, lane);
   const float b_l = bl[lane & 7], b_w = bw[lane & 7];
-  TH_STAMP(1);
-
 #pragma unroll 1
   for (int qb = qb0; qb < qb1; ++qb) {
     const int q0 = qb * FRB;
+    if (qb == qb0) TH_STAMP(1);
+    if (qb == qb0 + 1) TH_STAMP(6);
     // ---- phase S: S_w^T[key][q] = K Q^T, scaled, into plane w of every row
     {
       char* col = smem + n * ROWB + w * PLANE + 8 * kq;            // row = query n (+ 16 qbk), keys 16 kb + 4 kq + r
@@ -326,7 +356,9 @@ __global__ __launch_bounds__(512) void th_attn_fwd_kernel(const bf16* __restrict
       }
     }
     if (qb + 1 < qb1) load_q(qb + 1, qf);                           // the next block's query fragments travel under phase R
+    if (qb == qb0) TH_STAMP(2);
     __syncthreads();
+    if (qb == qb0) TH_STAMP(3);
 
     // ---- phase R: rows 4 w .. 4 w + 3: proj_l -> softmax -> proj_w, in place
 #pragma unroll 1
@@ -345,7 +377,9 @@ __global__ __launch_bounds__(512) void th_attn_fwd_kernel(const bf16* __restrict
         for (int r = 0; r < 4; ++r) d[t][r] += b_w;
       store_row(row, d, lane);                                     // P'
     }
+    if (qb == qb0) TH_STAMP(4);
     __syncthreads();
+    if (qb == qb0) TH_STAMP(5);
 
     // ---- phase PV: O_w^T[d][q] = V_w^T P'_w^T
     {
@@ -377,7 +411,7 @@ __global__ __launch_bounds__(512) void th_attn_fwd_kernel(const bf16* __restrict
       }
     }
   }
-  TH_STAMP(5);
+  TH_STAMP(7);
 }
 
 // ------------------------------------------------------------------------------------------------- backward ---
@@ -391,64 +425,94 @@ __global__ __launch_bounds__(512) void th_attn_bwd_kernel(const bf16* __restrict
                                                           const float* __restrict__ bl, const float* __restrict__ Ww,
                                                           const float* __restrict__ bw, bf16* __restrict__ dqkv,
                                                           bf16* __restrict__ dS_out, bf16* __restrict__ Pm_out, int64_t ld,
-                                                          float* __restrict__ part, int N, float scale,
+                                                          float* __restrict__ part, int N, float scale, int nblk, int nimg,
                                                           unsigned long long* __restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   TH_STAMP(0);
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nqb = (N + BRB - 1) / BRB;
-  const int b = blockIdx.x / nqb, q0 = (blockIdx.x % nqb) * BRB;
+  const int wpi = (nqb + nblk - 1) / nblk;                         // workgroups per image
+  // XCD-aware map: workgroups bid, bid + 8, ... share an XCD (and its L2); all workgroups of an image go to ONE XCD, so the
+  // image's fragment-major operands (504 KB) are fetched into that L2 once and shared by its row blocks.  (One workgroup
+  // walking a whole image, as in the forward, re-read them from beyond L2 for every block: 256 images in flight do not fit
+  // 8 x 4 MiB — 29 k + 31 k cycles of the 82 k per block.)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int b = (slot / wpi) * 8 + xcd;
+  if (b >= nimg) return;                                            // (grid padded to whole XCD rows; before any barrier)
+  const int qb0 = (slot % wpi) * nblk, qb1 = min(qb0 + nblk, nqb);
   const int64_t ts = 3 * TNH * THD, tso = TNH * THD;
   const int n = lane & 15, kq = lane >> 4;
+  const int bh = b * TNH + w;
 
-  // ---- phase S: head w: S^T[key][q] = K Q^T (scaled) and dP'^T[key][q] = V dO^T into planes w of the two arrays
-  {
-    const int qrow = min(q0 + n, N - 1);
-    const bf16* qp = qkv + ((int64_t)b * N + qrow) * ts + w * THD;
-    const bf16* dop = dout + ((int64_t)b * N + qrow) * tso + w * THD;
-    bf16x8 qf[2], df[2];
+  // (a resident K, as in the forward, does not fit: with the row phase's ~170 live registers hipcc spilled 158 dwords;
+  // K, V and K^T fragments are re-read per block from the fragment-major copies, one contiguous 0.5 - 1 KiB per load)
+  const char* kfu = rfK + (int64_t)bh * RF16_BYTES;                  // wave-uniform bases of this head's fragment-major operands
+  const char* vfu = rfV + (int64_t)bh * RF16_BYTES;
+  const char* ktu = tfK + (int64_t)bh * TF_BYTES;
+  auto load_qd = [&](int qb, bf16x4 (&qf)[3], bf16x4 (&df)[3]) {
+    const int qrow = min(qb * BRB + n, N - 1);
+    const bf16* qp = qkv + ((int64_t)b * N + qrow) * ts + w * THD + 4 * kq;
+    const bf16* dop = dout + ((int64_t)b * N + qrow) * tso + w * THD + 4 * kq;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) { qf[ks] = load_d8(qp, ks, kq); df[ks] = load_d8(dop, ks, kq); }
-    const char* kfp = rfK + (int64_t)(b * TNH + w) * RF_BYTES + lane * 16;
-    const char* vfp = rfV + (int64_t)(b * TNH + w) * RF_BYTES + lane * 16;
-    char* sa = smem + B_SA + n * ROWB + w * PLANE + 8 * kq;        // row = query n, keys 16 kb + 4 kq + r
-    char* da = smem + B_DA + n * ROWB + w * PLANE + 8 * kq;
+    for (int ks = 0; ks < 3; ++ks) { qf[ks] = *reinterpret_cast<const bf16x4*>(qp + 16 * ks); df[ks] = *reinterpret_cast<const bf16x4*>(dop + 16 * ks); }
+  };
+  bf16x4 qf[3], df[3];
+  load_qd(qb0, qf, df);
+  f32x4 gWw = {0.f, 0.f, 0.f, 0.f}, gWl = {0.f, 0.f, 0.f, 0.f};   // lane (n < 8, pq < 2): [g = 4 pq + r][h = n]
+  float dbw_acc = 0.f;
+  const float b_l = bl[lane & 7], b_w = bw[lane & 7];
+  const bf16x8 wl = mix_operand(Wl, false, lane), ww = mix_operand(Ww, false, lane);
+  const bf16x8 wlT = mix_operand(Wl, true, lane), wwT = mix_operand(Ww, true, lane);
+  char* sc = smem + B_SC + w * ROWB;                                // this wave's scratch row (planes)
+  const int p0 = 16 * (n >> 3) + 4 * kq;                            // D-layout position base of the lane (pq = kq)
 #pragma unroll 1
-    for (int half = 0; half < 2; ++half) {                          // 7 key blocks per batch of loads: two round trips
-      bf16x8 kf[7][2], vf[7][2];
+  for (int qb = qb0; qb < qb1; ++qb) {
+    const int q0 = qb * BRB;
+    if (qb == qb0) TH_STAMP(1);
+    if (qb == qb0 + 1) TH_STAMP(6);
+    // ---- phase S: head w: S^T[key][q] = K Q^T (scaled) and dP'^T[key][q] = V dO^T into planes w of the two arrays
+    {
+      char* sa = smem + B_SA + n * ROWB + w * PLANE + 8 * kq;      // row = query n, keys 16 kb + 4 kq + r
+      char* da = smem + B_DA + n * ROWB + w * PLANE + 8 * kq;
+      const float qvalid = (q0 + n < N) ? 1.f : 0.f;
+      // the row blocks of an image run side by side on one XCD and would ask its L2 for the same fragment at the same
+      // moment: block qb starts at key block qb (mod 14) — every tile is independent, the order is free
+      auto rotk = [&](int k) { const int x = k + qb; return x >= 14 ? x - 14 : x; };
+      auto s_half = [&](auto half_tag) {                            // 7 key blocks per batch of K / V fragment loads
+        constexpr int HALF = decltype(half_tag)::value;              // compile-time: a run-time index would put kf[] into scratch
+        bf16x4 kf[7][3], vf[7][3];
 #pragma unroll
-      for (int kk = 0; kk < 7; ++kk)
+        for (int kk = 0; kk < 7; ++kk)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          kf[kk][ks] = *reinterpret_cast<const bf16x8*>(kfp + ((7 * half + kk) * 2 + ks) * 1024);
-          vf[kk][ks] = *reinterpret_cast<const bf16x8*>(vfp + ((7 * half + kk) * 2 + ks) * 1024);
+          for (int ks = 0; ks < 3; ++ks) {
+            kf[kk][ks] = ldg_uu<bf16x4>(kfu, rotk(7 * HALF + kk) * 1536, (unsigned)(lane * 8), (unsigned)(ks * 512));
+            vf[kk][ks] = ldg_uu<bf16x4>(vfu, rotk(7 * HALF + kk) * 1536, (unsigned)(lane * 8), (unsigned)(ks * 512));
+          }
+#pragma unroll
+        for (int kk = 0; kk < 7; ++kk) {
+          constexpr int dummy = 0; (void)dummy;
+          const int kbk = rotk(7 * HALF + kk);
+          f32x4 sv = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 3; ++ks) { sv = mfma16k16(kf[kk][ks], qf[ks], sv); dp = mfma16k16(vf[kk][ks], df[ks], dp); }
+          bf16x4 s4 = {(bf16)(sv[0] * scale), (bf16)(sv[1] * scale), (bf16)(sv[2] * scale), (bf16)(sv[3] * scale)};
+          bf16x4 d4 = {(bf16)dp[0], (bf16)dp[1], (bf16)dp[2], (bf16)dp[3]};
+          dbw_acc += qvalid * ((dp[0] + dp[1]) + (dp[2] + dp[3]));   // d bw[w] = sum of dP'_w over valid (q, key): V's padded keys are zero rows
+          *reinterpret_cast<bf16x4*>(sa + 32 * kbk) = s4;
+          *reinterpret_cast<bf16x4*>(da + 32 * kbk) = d4;
         }
-#pragma unroll
-      for (int kk = 0; kk < 7; ++kk) {
-        const int kbk = 7 * half + kk;
-        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) { s = mfma16(kf[kk][ks], qf[ks], s); dp = mfma16(vf[kk][ks], df[ks], dp); }
-        bf16x4 sv = {(bf16)(s[0] * scale), (bf16)(s[1] * scale), (bf16)(s[2] * scale), (bf16)(s[3] * scale)};
-        bf16x4 dv = {(bf16)dp[0], (bf16)dp[1], (bf16)dp[2], (bf16)dp[3]};
-        *reinterpret_cast<bf16x4*>(sa + 32 * kbk) = sv;
-        *reinterpret_cast<bf16x4*>(da + 32 * kbk) = dv;
-      }
+      };
+      s_half(std::integral_constant<int, 0>{});
+      asm volatile("" ::: "memory");                                // keep the second batch of loads behind the first batch's products:
+      __builtin_amdgcn_sched_barrier(0);                            // hoisted together, 168 fragment registers spilled (157 dwords of scratch)
+      s_half(std::integral_constant<int, 1>{});
     }
-  }
-  TH_STAMP(1);
-  __syncthreads();
-  TH_STAMP(2);
+    if (qb == qb0) TH_STAMP(2);                                 // (stamps 1..7: the SECOND block of the walk, steady state)
+    __syncthreads();
+    if (qb == qb0) TH_STAMP(3);
 
-  // ---- phase R: rows 2 w, 2 w + 1
-  f32x4 gWw = {0.f, 0.f, 0.f, 0.f}, gWl = {0.f, 0.f, 0.f, 0.f};   // lane (n, pq): [g = 4 pq + r][n = h | 8: ones column]
-  {
-    const bf16x8 wl = mix_operand(Wl, false, lane), ww = mix_operand(Ww, false, lane);
-    const bf16x8 wlT = mix_operand(Wl, true, lane), wwT = mix_operand(Ww, true, lane);
-    const float b_l = bl[lane & 7], b_w = bw[lane & 7];
-    char* sc = smem + B_SC + w * ROWB;                              // this wave's scratch row (planes)
-    const int p0 = 16 * (n >> 3) + 4 * kq;                          // D-layout position base of the lane (pq = kq)
+    // ---- phase R: rows 2 w, 2 w + 1
 #pragma unroll 1
     for (int rr = 0; rr < BRB / 8; ++rr) {
       const int i = w * (BRB / 8) + rr;
@@ -466,15 +530,16 @@ __global__ __launch_bounds__(512) void th_attn_bwd_kernel(const bf16* __restrict
 #pragma unroll
         for (int r = 0; r < 4; ++r) dl += dP[t][r] * P[t][r];
       dl = head_sum(dl);
-      // parameter gradients, part 1: dWw[g,h] += sum_pos dP'_g P_h, dbw[g] += sum_pos dP'_g (ones column n = 8)
+      // dS' = P (dP - delta), kept in dP's registers
+#pragma unroll
+      for (int t = 0; t < 7; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dP[t][r] = P[t][r] * (dP[t][r] - dl);
+      // parameter gradients, part 1: dWw[g,h] += sum_pos dP'_g P_h  (dbw comes from phase S)
 #pragma unroll
       for (int t = 0; t < 7; ++t) {
         const bf16x8 a = *reinterpret_cast<const bf16x8*>(drow + (n & 7) * PLANE + (32 * t + 8 * kq) * 2);
-        bf16x8 bq = *reinterpret_cast<const bf16x8*>(sc + (n & 7) * PLANE + (32 * t + 8 * kq) * 2);
-        if (n == 8) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) bq[e] = (bf16)((32 * t + 8 * kq + e < N) ? 1.f : 0.f);
-        }
+        const bf16x8 bq = *reinterpret_cast<const bf16x8*>(sc + (n & 7) * PLANE + (32 * t + 8 * kq) * 2);
         gWw = mfma16(a, bq, gWw);
       }
       // P' = proj_w(P) -> HBM for the dV product
@@ -483,20 +548,12 @@ __global__ __launch_bounds__(512) void th_attn_bwd_kernel(const bf16* __restrict
         mix_row(sc, ww, pm, lane);
         bf16* po = Pm_out + (((int64_t)b * TNH + (n & 7)) * N + q0 + i) * ld + p0;
 #pragma unroll
-        for (int t = 0; t < 7; ++t) {
-          if (32 * t + p0 < N) {                                    // N % 4 == 0: a group of four is all valid or all padding
-            bf16x4 v = {(bf16)(pm[t][0] + b_w), (bf16)(pm[t][1] + b_w), (bf16)(pm[t][2] + b_w), (bf16)(pm[t][3] + b_w)};
-            *reinterpret_cast<bf16x4*>(po + 32 * t) = v;
-          }
+        for (int t = 0; t < 7; ++t) {                               // all 224 key slots: ld >= NKP, no per-tile branch around the store
+          bf16x4 v = {(bf16)(pm[t][0] + b_w), (bf16)(pm[t][1] + b_w), (bf16)(pm[t][2] + b_w), (bf16)(pm[t][3] + b_w)};
+          *reinterpret_cast<bf16x4*>(po + 32 * t) = v;
         }
       }
-      // dS' = P (dP - delta), into the scratch row
-      f32x4 dSp[7];
-#pragma unroll
-      for (int t = 0; t < 7; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dSp[t][r] = P[t][r] * (dP[t][r] - dl);
-      store_row(sc, dSp, lane);
+      store_row(sc, dP, lane);                                      // dS' planes -> scratch
       // parameter gradients, part 2: dWl[g,h] += sum_pos dS'_g S_h
 #pragma unroll
       for (int t = 0; t < 7; ++t) {
@@ -512,17 +569,46 @@ __global__ __launch_bounds__(512) void th_attn_bwd_kernel(const bf16* __restrict
         bf16* so = dS_out + (((int64_t)b * TNH + (n & 7)) * N + q0 + i) * ld + p0;
 #pragma unroll
         for (int t = 0; t < 7; ++t) {
-          if (32 * t + p0 < N) {
-            bf16x4 v = {(bf16)ds[t][0], (bf16)ds[t][1], (bf16)ds[t][2], (bf16)ds[t][3]};
-            *reinterpret_cast<bf16x4*>(so + 32 * t) = v;
-          }
+          bf16x4 v = {(bf16)ds[t][0], (bf16)ds[t][1], (bf16)ds[t][2], (bf16)ds[t][3]};
+          *reinterpret_cast<bf16x4*>(so + 32 * t) = v;
+        }
+      }
+    }
+    if (qb == qb0) TH_STAMP(4);
+    __syncthreads();
+    if (qb == qb0) TH_STAMP(5);
+
+    // ---- phase dQ: head w: dQ_w^T[d][q] = scale K_w^T dS_w^T (dS planes in the dP' array)
+    if (qb + 1 < qb1) load_qd(qb + 1, qf, df);                      // next block's q / dO fragments (not across phase R: registers)
+    {
+      f32x4 acc[3];
+#pragma unroll
+      for (int db = 0; db < 3; ++db) { acc[db][0] = 0.f; acc[db][1] = 0.f; acc[db][2] = 0.f; acc[db][3] = 0.f; }
+      auto rot7 = [&](int k) { const int x = k + qb % 7; return x >= 7 ? x - 7 : x; };
+      bf16x8 pf[7];
+#pragma unroll
+      for (int ks = 0; ks < 7; ++ks) pf[ks] = *reinterpret_cast<const bf16x8*>(smem + B_DA + n * ROWB + w * PLANE + (32 * rot7(ks) + 8 * kq) * 2);
+#pragma unroll
+      for (int db = 0; db < 3; ++db) {                              // 7 K^T fragments at a time: 28 registers, three round trips
+        bf16x8 ktf[7];
+#pragma unroll
+        for (int ks = 0; ks < 7; ++ks) ktf[ks] = ldg_uu<bf16x8>(ktu, (db * 7 + rot7(ks)) * 1024, (unsigned)(lane * 16), 0u);
+#pragma unroll
+        for (int ks = 0; ks < 7; ++ks) acc[db] = mfma16(ktf[ks], pf[ks], acc[db]);
+      }
+      const int q = q0 + n;
+      if (q < N) {
+        bf16* o = dqkv + ((int64_t)b * N + q) * ts + w * THD + 4 * kq;
+#pragma unroll
+        for (int db = 0; db < 3; ++db) {
+          bf16x4 v = {(bf16)(acc[db][0] * scale), (bf16)(acc[db][1] * scale), (bf16)(acc[db][2] * scale), (bf16)(acc[db][3] * scale)};
+          *reinterpret_cast<bf16x4*>(o + 16 * db) = v;
         }
       }
     }
   }
-  // per-workgroup partial sums of the parameter gradients: lanes (n < 8 | n == 8, pq < 2) hold [g = 4 pq + r][n]
-  TH_STAMP(3);
-  __syncthreads();                    // every wave is done with the S array: its first bytes become 8 slots of 160 floats
+  // ---- per-workgroup partial sums of the parameter gradients: lanes (n < 8 | n == 8, pq < 2) hold [g = 4 pq + r][n]
+  __syncthreads();                    // every wave is done with the arrays: the S array's first bytes become 8 slots of 160 floats
   {
     // one slot per wave, summed in wave order below: deterministic (LDS float atomics would add in arrival order)
     float* slot = reinterpret_cast<float*>(smem + B_SA) + w * 160;
@@ -531,46 +617,20 @@ __global__ __launch_bounds__(512) void th_attn_bwd_kernel(const bf16* __restrict
       for (int r = 0; r < 4; ++r) {
         const int g = 4 * kq + r;
         if (n < 8) { slot[g * TNH + n] = gWl[r]; slot[TNH * TNH + TNH + g * TNH + n] = gWw[r]; }
-        if (n == 8) { slot[TNH * TNH + g] = 0.f; slot[2 * TNH * TNH + TNH + g] = gWw[r]; }
       }
     }
+    const float dbw_w = wave_sum(dbw_acc);                          // this wave's head
+    if (lane < 16) slot[(lane < 8 ? TNH * TNH : 2 * TNH * TNH + TNH) + (lane & 7)] = (lane >= 8 && (lane & 7) == w) ? dbw_w : 0.f;
   }
   __syncthreads();
   if (threadIdx.x < TH_PART) {
     const float* slots = reinterpret_cast<const float*>(smem + B_SA);
-    float s = 0.f;
+    float sum = 0.f;
 #pragma unroll
-    for (int ww_ = 0; ww_ < 8; ++ww_) s += slots[ww_ * 160 + threadIdx.x];
-    part[(int64_t)blockIdx.x * TH_PART + threadIdx.x] = s;
+    for (int ww_ = 0; ww_ < 8; ++ww_) sum += slots[ww_ * 160 + threadIdx.x];
+    part[((int64_t)b * wpi + slot % wpi) * TH_PART + threadIdx.x] = sum;
   }
-
-  TH_STAMP(4);
-  // ---- phase dQ: head w: dQ_w^T[d][q] = scale K_w^T dS_w^T (dS planes in the dP' array)
-  {
-    const char* ktp = tfK + (int64_t)(b * TNH + w) * TF_BYTES + lane * 16;
-    f32x4 acc[3];
-#pragma unroll
-    for (int db = 0; db < 3; ++db) { acc[db][0] = 0.f; acc[db][1] = 0.f; acc[db][2] = 0.f; acc[db][3] = 0.f; }
-#pragma unroll
-    for (int ks = 0; ks < 7; ++ks) {
-      const bf16x8 pf = *reinterpret_cast<const bf16x8*>(smem + B_DA + n * ROWB + w * PLANE + (32 * ks + 8 * kq) * 2);
-#pragma unroll
-      for (int db = 0; db < 3; ++db) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ktp + (db * 7 + ks) * 1024);
-        acc[db] = mfma16(kf, pf, acc[db]);
-      }
-    }
-    const int q = q0 + n;
-    if (q < N) {
-      bf16* o = dqkv + ((int64_t)b * N + q) * ts + w * THD + 4 * kq;
-#pragma unroll
-      for (int db = 0; db < 3; ++db) {
-        bf16x4 v = {(bf16)(acc[db][0] * scale), (bf16)(acc[db][1] * scale), (bf16)(acc[db][2] * scale), (bf16)(acc[db][3] * scale)};
-        *reinterpret_cast<bf16x4*>(o + 16 * db) = v;
-      }
-    }
-  }
-  TH_STAMP(5);
+  TH_STAMP(7);
 }
 
 }  // namespace
@@ -587,7 +647,7 @@ extern "C" int vitmi_th_attn_supported(int dtype, int64_t H, int64_t N, int64_t 
 // parameter-gradient partials
 extern "C" size_t vitmi_th_attn_workspace(int64_t B, int64_t H, int64_t N, int64_t hd) {
   (void)hd;
-  const size_t packs = (size_t)B * H * (2 * RF_BYTES + TF_BYTES);
+  const size_t packs = (size_t)B * H * (2 * RF16_BYTES + TF_BYTES);
   const size_t parts = (size_t)B * ((N + BRB - 1) / BRB) * TH_PART * sizeof(float);
   return packs + ((parts + 255) / 256) * 256;
 }
@@ -623,23 +683,26 @@ extern "C" int vitmi_th_attn_bwd(const void* qkv, const void* dout, const float*
                                  void* workspace, size_t workspace_bytes, void* stream_) {
   VITMI_REQUIRE(qkv && dout && Wl && bl && Ww && bw && dqkv && dS && Pm && dWl && dbl && dWw && dbw && B > 0, VITMI_E_BADARG, "th_attn_bwd: null argument");
   VITMI_REQUIRE(vitmi_th_attn_supported(dtype, H, N, hd), VITMI_E_SHAPE, "th_attn_bwd: bf16, H = 8, hd = 48, N <= 224 and N %% 4 == 0 required");
-  VITMI_REQUIRE(ld >= N && ld % 4 == 0 && is_aligned(dS, 8) && is_aligned(Pm, 8) && is_aligned(qkv, 16) && is_aligned(dout, 16) && is_aligned(dqkv, 8),
-                VITMI_E_ALIGN, "th_attn_bwd: ld %% 4 == 0 and 8 / 16-byte aligned operands required");
+  VITMI_REQUIRE(ld >= NKP && ld % 4 == 0 && is_aligned(dS, 8) && is_aligned(Pm, 8) && is_aligned(qkv, 16) && is_aligned(dout, 16) && is_aligned(dqkv, 8),
+                VITMI_E_ALIGN, "th_attn_bwd: ld >= 224 (every key slot of a row is written), ld %% 4 == 0 and 8 / 16-byte aligned operands required");
   VITMI_REQUIRE(workspace && is_aligned(workspace, 256) && workspace_bytes >= vitmi_th_attn_workspace(B, H, N, hd), VITMI_E_WORKSPACE, "th_attn_bwd: workspace too small or misaligned");
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   char* rfK = reinterpret_cast<char*>(workspace);
-  char* rfV = rfK + (size_t)B * H * RF_BYTES;
-  char* tfK = rfV + (size_t)B * H * RF_BYTES;
+  char* rfV = rfK + (size_t)B * H * RF16_BYTES;
+  char* tfK = rfV + (size_t)B * H * RF16_BYTES;
   float* part = reinterpret_cast<float*>(tfK + (size_t)B * H * TF_BYTES);
   const bf16* q = reinterpret_cast<const bf16*>(qkv);
   hipLaunchKernelGGL(th_pack_kernel<true>, dim3((unsigned)(B * H)), dim3(256), 0, stream, q, rfK, rfV, tfK, (int)N, (int)H);
   if (int rc = vitmi_check_launch("th_pack_kernel")) return rc;
   if (int rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(th_attn_bwd_kernel), B_LDS, "th_attn_bwd")) return rc;
   const int64_t nqb = (N + BRB - 1) / BRB;
-  hipLaunchKernelGGL(th_attn_bwd_kernel, dim3((unsigned)(B * nqb)), dim3(512), B_LDS, stream, q, reinterpret_cast<const bf16*>(dout), rfK, rfV, tfK, Wl, bl, Ww, bw,
-                     reinterpret_cast<bf16*>(dqkv), reinterpret_cast<bf16*>(dS), reinterpret_cast<bf16*>(Pm), ld, part, (int)N, scale, g_th_dbg.load());
+  const int nblk = 1;                                                // one block per workgroup: an image's blocks share its operands in L2
+  const int64_t wpi = (nqb + nblk - 1) / nblk;
+  const int64_t img_rows = (B + 7) / 8;                              // images per XCD
+  hipLaunchKernelGGL(th_attn_bwd_kernel, dim3((unsigned)(8 * img_rows * wpi)), dim3(512), B_LDS, stream, q, reinterpret_cast<const bf16*>(dout), rfK, rfV, tfK, Wl, bl, Ww, bw,
+                     reinterpret_cast<bf16*>(dqkv), reinterpret_cast<bf16*>(dS), reinterpret_cast<bf16*>(Pm), ld, part, (int)N, scale, nblk, (int)B, g_th_dbg.load());
   if (int rc = vitmi_check_launch("th_attn_bwd_kernel")) return rc;
   float* const outs[4] = {dWl, dbl, dWw, dbw};
   const int widths[4] = {TNH * TNH, TNH, TNH * TNH, TNH};
-  return vitmi_reduce_rows_segs(part, (int)(B * nqb), TH_PART, outs, widths, stream);
+  return vitmi_reduce_rows_segs(part, (int)(B * wpi), TH_PART, outs, widths, stream);
 }
