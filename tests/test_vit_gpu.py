@@ -349,3 +349,48 @@ def test_second_backward_accumulates(compute):
     crit(m(xb.cuda()), yb.cuda()).backward()
     for p, gb in zip(m.parameters(), singles[1]):
         torch.testing.assert_close(p.grad, gb, rtol=1e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------- CLS-only last block (opt-in) ---
+@pytest.mark.parametrize("compute,residual", [("fp32", "fp32"), ("bf16", "bf16"), ("bf16", "fp32")])
+def test_cls_only_last_block_gives_the_same_step(compute, residual):
+    """`cls_only_last_block=True`: the model returns norm(x)[:, 0], so the last block's attention output, proj and MLP are
+    needed on the CLS row only (k / v still from all tokens) and only that row sends a gradient back.  Same weights, same
+    batch: logits, loss and EVERY gradient (the last block's included: its weight gradients are sums over rows of which
+    all but the CLS ones are exactly zero in the full computation) must equal the full computation's, and the oracle's."""
+    from vit_torch_amd import CrossEntropyLoss, VisionTransformer, VisionModelZoo
+    cfg = dict(img_size=64, patch_size=16, in_chans=3, embed_dim=128, depth=3, num_heads=2)      # N = 17: ragged M = 17 B
+    ref, full = make_pair(cfg, 10, compute, residual)
+    x, y = data(24, 3, 64, 10, seed=7)
+    m = VisionTransformer(**cfg, apply_head=True, compute_dtype=compute, residual_dtype=residual, cls_only_last_block=True)
+    m.head = VisionModelZoo.get_classifier_head(cfg["embed_dim"], 10)
+    m.load_state_dict(ref.state_dict(), strict=True)
+    m = m.cuda()
+    crit = CrossEntropyLoss()
+    res = []
+    for mod in (full, m):
+        out = mod(x.cuda())
+        loss = crit(out, y.cuda())
+        mod.zero_grad()
+        loss.backward()
+        res.append((out.detach().float().cpu(), loss.item(), {n: p.grad.detach().float().cpu() for n, p in mod.named_parameters()}))
+    assert m.engine().cls_last and not full.engine().cls_last
+    tol = 2e-5 if compute == "fp32" else 8e-3
+    assert_close("logits", res[1][0], res[0][0], tol)
+    assert abs(res[1][1] - res[0][1]) < (1e-5 if compute == "fp32" else 2e-3)
+    gmax = max(g.norm().item() for g in res[0][2].values())
+    for n, g0 in res[0][2].items():
+        g1 = res[1][2][n]
+        if g0.norm().item() < 1e-6 * gmax:
+            assert g1.norm().item() < 1e-4 * gmax, n
+            continue
+        assert_close(f"grad[{n}]", g1, g0, 1e-4 if compute == "fp32" else 4e-2)
+    # and against the oracle (fp32 mode: the parity claim holds with the option on)
+    if compute == "fp32":
+        lo = ref(x)
+        lr = F.cross_entropy(lo, y)
+        ref.zero_grad(); lr.backward()
+        assert_close("logits vs oracle", res[1][0], lo.detach(), 1e-4)
+        for (n, pr) in ref.named_parameters():
+            if pr.grad is not None and pr.grad.abs().max().item() > 1e-9:
+                assert_close(f"grad[{n}] vs oracle", res[1][2][n], pr.grad, 3e-4)
