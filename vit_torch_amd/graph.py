@@ -85,6 +85,14 @@ class GraphedStep:
                 self.warm_out, self.warm_loss = out.detach().clone(), loss.detach().clone()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        eng_ = self.model.engine() if hasattr(self.model, "engine") else None
+        if getattr(eng_, "reducer", None) is not None:
+            # ProcessGroupNCCL's watchdog thread polls the events of the eager warm-up's collectives every 100 ms and ABORTS the
+            # process when a query fails ("operation not permitted on an event last recorded in a capturing stream": seen once in
+            # round 4, beside a capture).  Everything eager has completed (synchronize above): let the watchdog retire it before
+            # the capture starts, so that it holds nothing while the stream captures.
+            import time
+            time.sleep(0.35)
         # The engine's fp32 -> bf16 weight cast stays OUT of the graph when the captured optimizer is one of the fused ones
         # over ALL of the pack's trainable parameters: those kernels write master and shadow in one pass, so inside the
         # replay loop the shadow is always current, and __call__ checks the pack's version key eagerly before every replay
