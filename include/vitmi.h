@@ -253,10 +253,9 @@ int vitmi_th_softmax_bwd(const void* S, const void* P, const void* dPm, const fl
 /* Talking-heads attention as ONE op (ABI 108; models/cait.py:111-128): O = proj_w(softmax(proj_l(scale q k^T))) v with the
  * score rows resident in LDS and both head mixes on the matrix pipe; the forward keeps nothing but O.  bf16, H = 8,
  * hd = 48, N <= 224, N % 4 == 0 (vitmi_th_attn_supported); other shapes / fp32 take the three-call form above.
- * qkv [B,N,3,H,hd], out / dout [B,N,H,hd].  The backward recomputes the scores, writes dQ into the q slots of dqkv, the
- * four proj_l / proj_w gradients (fp32, overwritten), and hands dS and Pm = P' ([B,H,N,ld] bf16) to the caller's two
- * remaining batched products (dK = scale dS^T q, dV = Pm^T dout); ld >= 224: all 224 key slots of a row are written (columns
- * >= N are padding).  workspace: vitmi_th_attn_workspace bytes, 256-B aligned. */
+ * qkv [B,N,3,H,hd], out / dout [B,N,H,hd].  The backward recomputes the scores and writes dqkv (all of it) and the four
+ * proj_l / proj_w gradients (fp32, overwritten); dS and Pm ([B,H,N,ld] bf16, ld >= 224) are caller-owned SCRATCH through
+ * which dS and P' travel once between its two kernels (the row kernel and the dQ / dK / dV products).  workspace: vitmi_th_attn_workspace bytes, 256-B aligned. */
 int vitmi_th_attn_supported(int dtype, int64_t H, int64_t N, int64_t hd);
 size_t vitmi_th_attn_workspace(int64_t B, int64_t H, int64_t N, int64_t hd);
 int vitmi_th_attn_fwd(const void* qkv, const float* Wl, const float* bl, const float* Ww, const float* bw,

@@ -51,11 +51,6 @@ def fused(ops, qkv, dO, Wl, bl, Ww, bw, scale):
     gr = [torch.full((H, H), float("nan"), device=dev), torch.full((H,), float("nan"), device=dev),
           torch.full((H, H), float("nan"), device=dev), torch.full((H,), float("nan"), device=dev)]
     ops.th_attn_bwd(q, do, *W, dqkv, dS, Pm, NS, *gr, B, H, N, hd, scale)
-    q2, do2 = q.view(B * N, D3), do.view(B * N, D)
-    ops.gemm_batched(Pm, do2, dqkv, M=N, N=hd, K=N, lda=NS, ldb=D, ldc=D3, a_kmajor=False, b_kmajor=False,
-                     batch=B * H, batch_inner=H, a_bs=(H * N * NS, N * NS), b_bs=(N * D, hd), c_bs=(N * D3, hd), c_off=2 * D)
-    ops.gemm_batched(dS, q2, dqkv, M=N, N=hd, K=N, lda=NS, ldb=D3, ldc=D3, a_kmajor=False, b_kmajor=False,
-                     batch=B * H, batch_inner=H, a_bs=(H * N * NS, N * NS), b_bs=(N * D3, hd), c_bs=(N * D3, hd), c_off=D, alpha=scale)
     torch.cuda.synchronize()
     return O.float().cpu().reshape(B, N, D), dqkv.float().cpu().view(B, N, 3, H, hd), [t.cpu() for t in gr]
 

@@ -62,12 +62,11 @@ def bwdf_k():
 
 def bwdf():
     bwdf_k()
-    dkdv()
 
 
 print(f"B={B} N={N} H={H} hd={hd}: us per layer")
 print(f"  forward : three calls {timed(fwd3):7.1f}   fused {timed(fwdf):7.1f}")
-print(f"  backward: three calls + 4 products {timed(bwd3):7.1f}   fused kernel {timed(bwdf_k):7.1f} + dK / dV products {timed(dkdv):7.1f} = {timed(bwdf):7.1f}")
+print(f"  backward: three calls + 4 products {timed(bwd3):7.1f}   fused (pack + row kernel + products kernel) {timed(bwdf):7.1f}")
 
 import ctypes, numpy as np
 from vit_torch_amd import _lib

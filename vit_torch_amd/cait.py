@@ -485,9 +485,9 @@ class CaitEngine:
             # talking-heads attention backward
             dqkv = new(M, D3, T)
             if S is None:
-                # fused form: the scores are recomputed inside the kernel, which also forms dP' = dO v^T, runs the softmax
-                # backward through both mixes, writes dQ and the four mixing-parameter gradients, and leaves dS and P' for
-                # the two products whose contraction runs over the QUERIES
+                # fused form: the scores are recomputed inside the row kernel, which also forms dP' = dO v^T, runs the softmax
+                # backward through both mixes and writes the four mixing-parameter gradients; dS and P' (scratch here) go
+                # through HBM once to the products kernel, which writes dQ, dK and dV
                 NSb = 224                # the kernel writes all 224 key slots of a score row (no per-tile store branches)
                 dS = torch.empty((B, H, Np, NSb), dtype=T, device=dev)
                 Pm = torch.empty((B, H, Np, NSb), dtype=T, device=dev)
@@ -506,13 +506,13 @@ class CaitEngine:
                 ops.gemm_batched(dS, qkv, dqkv, M=Np, N=hd, K=Np, lda=NS, ldb=D3, ldc=D3, a_kmajor=True, b_kmajor=False,
                                  batch=B * H, batch_inner=H, a_bs=(H * Np * NS, Np * NS), b_bs=(Np * D3, hd),
                                  c_bs=(Np * D3, hd), b_off=D, alpha=a.scale)                          # dQ = scale dS K
-            NSd = dS.shape[-1]
-            ops.gemm_batched(Pm, dO, dqkv, M=Np, N=hd, K=Np, lda=NSd, ldb=D, ldc=D3, a_kmajor=False, b_kmajor=False,
-                             batch=B * H, batch_inner=H, a_bs=(H * Np * NSd, Np * NSd), b_bs=(Np * D, hd),
-                             c_bs=(Np * D3, hd), c_off=2 * D)                                   # dV = P'^T dO
-            ops.gemm_batched(dS, qkv, dqkv, M=Np, N=hd, K=Np, lda=NSd, ldb=D3, ldc=D3, a_kmajor=False, b_kmajor=False,
-                             batch=B * H, batch_inner=H, a_bs=(H * Np * NSd, Np * NSd), b_bs=(Np * D3, hd),
-                             c_bs=(Np * D3, hd), c_off=D, alpha=a.scale)                          # dK = scale dS^T Q
+            if S is not None:            # three-call form: the two products that contract over the queries
+                ops.gemm_batched(Pm, dO, dqkv, M=Np, N=hd, K=Np, lda=NS, ldb=D, ldc=D3, a_kmajor=False, b_kmajor=False,
+                                 batch=B * H, batch_inner=H, a_bs=(H * Np * NS, Np * NS), b_bs=(Np * D, hd),
+                                 c_bs=(Np * D3, hd), c_off=2 * D)                                   # dV = P'^T dO
+                ops.gemm_batched(dS, qkv, dqkv, M=Np, N=hd, K=Np, lda=NS, ldb=D3, ldc=D3, a_kmajor=False, b_kmajor=False,
+                                 batch=B * H, batch_inner=H, a_bs=(H * Np * NS, Np * NS), b_bs=(Np * D3, hd),
+                                 c_bs=(Np * D3, hd), c_off=D, alpha=a.scale)                          # dK = scale dS^T Q
             dln1 = new(M, D, T)
             self._gemm(dqkv, self._w(a.qkv.weight), dln1, b_kmajor=False)
             self._gemm(dqkv, ln1, pk.g(a.qkv.weight), a_kmajor=False, b_kmajor=False)

@@ -421,7 +421,7 @@ constexpr int TH_PART = 2 * TNH * TNH + 2 * TNH;     // dWl | dbl | dWw | dbw pe
 
 __global__ __launch_bounds__(512) void th_attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
                                                           const char* __restrict__ rfK, const char* __restrict__ rfV,
-                                                          const char* __restrict__ tfK, const float* __restrict__ Wl,
+                                                          const float* __restrict__ Wl,
                                                           const float* __restrict__ bl, const float* __restrict__ Ww,
                                                           const float* __restrict__ bw, bf16* __restrict__ dqkv,
                                                           bf16* __restrict__ dS_out, bf16* __restrict__ Pm_out, int64_t ld,
@@ -449,7 +449,6 @@ __global__ __launch_bounds__(512) void th_attn_bwd_kernel(const bf16* __restrict
   // K, V and K^T fragments are re-read per block from the fragment-major copies, one contiguous 0.5 - 1 KiB per load)
   const char* kfu = rfK + (int64_t)bh * RF16_BYTES;                  // wave-uniform bases of this head's fragment-major operands
   const char* vfu = rfV + (int64_t)bh * RF16_BYTES;
-  const char* ktu = tfK + (int64_t)bh * TF_BYTES;
   auto load_qd = [&](int qb, bf16x4 (&qf)[3], bf16x4 (&df)[3]) {
     const int qrow = min(qb * BRB + n, N - 1);
     const bf16* qp = qkv + ((int64_t)b * N + qrow) * ts + w * THD + 4 * kq;
@@ -561,11 +560,10 @@ __global__ __launch_bounds__(512) void th_attn_bwd_kernel(const bf16* __restrict
         const bf16x8 bq = *reinterpret_cast<const bf16x8*>(srow + (n & 7) * PLANE + (32 * t + 8 * kq) * 2);
         gWl = mfma16(a, bq, gWl);
       }
-      // dS_h = sum_g Wl[g,h] dS'_g -> planes of the dP' array's row (phase dQ) and HBM (the dK product)
+      // dS_h = sum_g Wl[g,h] dS'_g -> HBM (th_attn_prod_kernel: dQ, dK)
       {
         f32x4 ds[7];
         mix_row(sc, wlT, ds, lane);
-        store_row(drow, ds, lane);
         bf16* so = dS_out + (((int64_t)b * TNH + (n & 7)) * N + q0 + i) * ld + p0;
 #pragma unroll
         for (int t = 0; t < 7; ++t) {
@@ -578,34 +576,6 @@ __global__ __launch_bounds__(512) void th_attn_bwd_kernel(const bf16* __restrict
     __syncthreads();
     if (qb == qb0) TH_STAMP(5);
 
-    // ---- phase dQ: head w: dQ_w^T[d][q] = scale K_w^T dS_w^T (dS planes in the dP' array)
-    if (qb + 1 < qb1) load_qd(qb + 1, qf, df);                      // next block's q / dO fragments (not across phase R: registers)
-    {
-      f32x4 acc[3];
-#pragma unroll
-      for (int db = 0; db < 3; ++db) { acc[db][0] = 0.f; acc[db][1] = 0.f; acc[db][2] = 0.f; acc[db][3] = 0.f; }
-      auto rot7 = [&](int k) { const int x = k + qb % 7; return x >= 7 ? x - 7 : x; };
-      bf16x8 pf[7];
-#pragma unroll
-      for (int ks = 0; ks < 7; ++ks) pf[ks] = *reinterpret_cast<const bf16x8*>(smem + B_DA + n * ROWB + w * PLANE + (32 * rot7(ks) + 8 * kq) * 2);
-#pragma unroll
-      for (int db = 0; db < 3; ++db) {                              // 7 K^T fragments at a time: 28 registers, three round trips
-        bf16x8 ktf[7];
-#pragma unroll
-        for (int ks = 0; ks < 7; ++ks) ktf[ks] = ldg_uu<bf16x8>(ktu, (db * 7 + rot7(ks)) * 1024, (unsigned)(lane * 16), 0u);
-#pragma unroll
-        for (int ks = 0; ks < 7; ++ks) acc[db] = mfma16(ktf[ks], pf[ks], acc[db]);
-      }
-      const int q = q0 + n;
-      if (q < N) {
-        bf16* o = dqkv + ((int64_t)b * N + q) * ts + w * THD + 4 * kq;
-#pragma unroll
-        for (int db = 0; db < 3; ++db) {
-          bf16x4 v = {(bf16)(acc[db][0] * scale), (bf16)(acc[db][1] * scale), (bf16)(acc[db][2] * scale), (bf16)(acc[db][3] * scale)};
-          *reinterpret_cast<bf16x4*>(o + 16 * db) = v;
-        }
-      }
-    }
   }
   // ---- per-workgroup partial sums of the parameter gradients: lanes (n < 8 | n == 8, pq < 2) hold [g = 4 pq + r][n]
   __syncthreads();                    // every wave is done with the arrays: the S array's first bytes become 8 slots of 160 floats
@@ -631,6 +601,142 @@ __global__ __launch_bounds__(512) void th_attn_bwd_kernel(const bf16* __restrict
     part[((int64_t)b * wpi + slot % wpi) * TH_PART + threadIdx.x] = sum;
   }
   TH_STAMP(7);
+}
+
+// ------------------------------------------------------------------------- backward: the three operand gradients ---
+// dQ = scale dS K, dK = scale dS^T Q, dV = P'^T dO for one (image, head) per workgroup, from the dS / P' rows the row kernel
+// left in HBM (each read ONCE; the two batched gemm_small calls read them at 2.3 TB/s and took 150 us per layer, and dQ
+// inside the row kernel cost it a third operand phase).  Half of the [query][key] image at a time sits in LDS (464-B rows,
+// 64.5 KB with the q / dO rows: two workgroups per CU, one's staging under the other's products); the products
+// that contract over QUERIES take both operands through ds_read_b64_tr_b16 from row-major [query][.] images (the
+// fragment of v_mfma_f32_16x16x16_bf16 is exactly what one transposing read delivers); dQ contracts over keys: K^T
+// fragments from the fragment-major copy, dS rows as plain 16-B reads.
+constexpr int PH = NKP / 2;                           // query rows staged at a time: the contraction over queries runs in two halves
+constexpr int PS_PITCH = NKP * 2 + 16, PQ_PITCH = THD * 2 + 16;
+constexpr int P_IMG_S = 0, P_IMG_Q = PH * PS_PITCH, P_LDS = PH * PS_PITCH + PH * PQ_PITCH;     // 64.5 KB: two workgroups per CU
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void th_attn_prod_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
+                                                           const bf16* __restrict__ dS, const bf16* __restrict__ Pm, int64_t ld,
+                                                           const char* __restrict__ tfK, bf16* __restrict__ dqkv, int N, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bh = blockIdx.x, b = bh / TNH, h = bh % TNH;
+  const int64_t ts = 3 * TNH * THD, tso = TNH * THD;
+  const int n = lane & 15, kq = lane >> 4;
+  char* imgS = smem + P_IMG_S;
+  char* imgQ = smem + P_IMG_Q;
+  // rows [r0, r0 + PH) of a [N][cols] bf16 matrix (row stride rs elements) -> LDS image with `pitch`-byte rows, rows >= N zeroed
+  // (all loads of a batch are issued before the first store: as a load -> store loop every 16-B piece paid its own round trip)
+  auto stage = [&](char* img, int pitch, const bf16* src, int64_t rs, int r0, auto cols8_tag) {
+    constexpr int COLS8 = decltype(cols8_tag)::value;
+    constexpr int IT = (PH * COLS8 + 511) / 512;
+#pragma unroll
+    for (int i0 = 0; i0 < IT; i0 += 4) {
+      bf16x8 v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i0 + i < IT) {
+          const int c = min(tid + (i0 + i) * 512, PH * COLS8 - 1);
+          v[i] = *reinterpret_cast<const bf16x8*>(src + (int64_t)min(r0 + c / COLS8, N - 1) * rs + (c % COLS8) * 8);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = tid + (i0 + i) * 512;
+        if (i0 + i < IT && c < PH * COLS8) {
+          const int row = c / COLS8;
+          *reinterpret_cast<bf16x8*>(img + row * pitch + (c % COLS8) * 16) = r0 + row < N ? v[i] : zero8();
+        }
+      }
+    }
+  };
+  // this wave's column blocks of the [d][key] products: cb = w and w + 8 (14 blocks: waves 6, 7 have one); all three d-blocks
+  // of a column block share its B fragments
+  f32x4 acc[2][3];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int db = 0; db < 3; ++db) { acc[u][db][0] = 0.f; acc[u][db][1] = 0.f; acc[u][db][2] = 0.f; acc[u][db][3] = 0.f; }
+  };
+  // acc[u][db] += sum over the PH staged query rows of X[q][16 db + .] Y[q][16 cb_u + .]   (X in imgQ, Y in imgS)
+  auto contract_q = [&]() {
+    const int i = lane & 15;
+    const char* pa = imgQ + (4 * kq + (i >> 2)) * PQ_PITCH + (4 * (i & 3)) * 2;
+    const char* pb = imgS + (4 * kq + (i >> 2)) * PS_PITCH + (4 * (i & 3)) * 2;
+#pragma unroll 1
+    for (int qb = 0; qb < PH / 16; ++qb) {
+      bf16x4 a[3];
+#pragma unroll
+      for (int db = 0; db < 3; ++db) a[db] = tr4(pa + qb * 16 * PQ_PITCH + 32 * db);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int cb = w + 8 * u;
+        if (cb < 14) {                                               // wave-uniform
+          const bf16x4 bfr = tr4(pb + qb * 16 * PS_PITCH + 32 * cb);
+#pragma unroll
+          for (int db = 0; db < 3; ++db) acc[u][db] = mfma16k16(a[db], bfr, acc[u][db]);
+        }
+      }
+    }
+  };
+  auto store_cols = [&](int slot_off, float mul) {                  // acc[u][db] = D^T[d = 16 db + 4 kq + r][key = 16 cb_u + n]
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int key = 16 * (w + 8 * u) + n;
+      if (w + 8 * u < 14 && key < N) {
+#pragma unroll
+        for (int db = 0; db < 3; ++db) {
+          bf16x4 v = {(bf16)(acc[u][db][0] * mul), (bf16)(acc[u][db][1] * mul), (bf16)(acc[u][db][2] * mul), (bf16)(acc[u][db][3] * mul)};
+          *reinterpret_cast<bf16x4*>(dqkv + ((int64_t)b * N + key) * ts + slot_off + h * THD + 16 * db + 4 * kq) = v;
+        }
+      }
+    }
+  };
+  // dQ: wave w owns d-block w % 3 (its 7 K^T fragments stay in 28 registers) and every (waves on that d-block)-th row block
+  const int qdb = w % 3, qfirst = w / 3, qstep = qdb < 2 ? 3 : 2;
+  bf16x8 ktf[7];
+  {
+    const char* ktu = tfK + (int64_t)bh * TF_BYTES + lane * 16;
+#pragma unroll
+    for (int ks = 0; ks < 7; ++ks) ktf[ks] = *reinterpret_cast<const bf16x8*>(ktu + (qdb * 7 + ks) * 1024);
+  }
+  // ---- dK^T[d][key] = scale sum_q Q[q][d] dS[q][key]  and  dQ^T[d][q] = scale sum_key K[key][d] dS[q][key]
+  zero_acc();
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    if (half) __syncthreads();
+    stage(imgS, PS_PITCH, dS + (int64_t)bh * N * ld, ld, half * PH, std::integral_constant<int, NKP / 8>{});
+    stage(imgQ, PQ_PITCH, qkv + (int64_t)b * N * ts + h * THD, ts, half * PH, std::integral_constant<int, THD / 8>{});
+    __syncthreads();
+    contract_q();
+#pragma unroll 1
+    for (int qb = qfirst; qb < PH / 16; qb += qstep) {             // dQ of the staged rows
+      f32x4 aq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 7; ++ks) {
+        const bf16x8 pf = *reinterpret_cast<const bf16x8*>(imgS + (16 * qb + n) * PS_PITCH + (32 * ks + 8 * kq) * 2);
+        aq = mfma16(ktf[ks], pf, aq);
+      }
+      const int q = half * PH + 16 * qb + n;
+      if (q < N) {
+        bf16x4 v = {(bf16)(aq[0] * scale), (bf16)(aq[1] * scale), (bf16)(aq[2] * scale), (bf16)(aq[3] * scale)};
+        *reinterpret_cast<bf16x4*>(dqkv + ((int64_t)b * N + q) * ts + h * THD + 16 * qdb + 4 * kq) = v;
+      }
+    }
+  }
+  store_cols((int)tso, scale);
+  // ---- dV^T[d][key] = sum_q dO[q][d] P'[q][key]
+  zero_acc();
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+    stage(imgS, PS_PITCH, Pm + (int64_t)bh * N * ld, ld, half * PH, std::integral_constant<int, NKP / 8>{});
+    stage(imgQ, PQ_PITCH, dout + (int64_t)b * N * tso + h * THD, tso, half * PH, std::integral_constant<int, THD / 8>{});
+    __syncthreads();
+    contract_q();
+  }
+  store_cols((int)(2 * tso), 1.f);
 }
 
 }  // namespace
@@ -699,9 +805,13 @@ extern "C" int vitmi_th_attn_bwd(const void* qkv, const void* dout, const float*
   const int nblk = 1;                                                // one block per workgroup: an image's blocks share its operands in L2
   const int64_t wpi = (nqb + nblk - 1) / nblk;
   const int64_t img_rows = (B + 7) / 8;                              // images per XCD
-  hipLaunchKernelGGL(th_attn_bwd_kernel, dim3((unsigned)(8 * img_rows * wpi)), dim3(512), B_LDS, stream, q, reinterpret_cast<const bf16*>(dout), rfK, rfV, tfK, Wl, bl, Ww, bw,
+  hipLaunchKernelGGL(th_attn_bwd_kernel, dim3((unsigned)(8 * img_rows * wpi)), dim3(512), B_LDS, stream, q, reinterpret_cast<const bf16*>(dout), rfK, rfV, Wl, bl, Ww, bw,
                      reinterpret_cast<bf16*>(dqkv), reinterpret_cast<bf16*>(dS), reinterpret_cast<bf16*>(Pm), ld, part, (int)N, scale, nblk, (int)B, g_th_dbg.load());
   if (int rc = vitmi_check_launch("th_attn_bwd_kernel")) return rc;
+  if (int rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(th_attn_prod_kernel), P_LDS, "th_attn_bwd(products)")) return rc;
+  hipLaunchKernelGGL(th_attn_prod_kernel, dim3((unsigned)(B * H)), dim3(512), P_LDS, stream, q, reinterpret_cast<const bf16*>(dout),
+                     reinterpret_cast<const bf16*>(dS), reinterpret_cast<const bf16*>(Pm), ld, tfK, reinterpret_cast<bf16*>(dqkv), (int)N, scale);
+  if (int rc = vitmi_check_launch("th_attn_prod_kernel")) return rc;
   float* const outs[4] = {dWl, dbl, dWw, dbw};
   const int widths[4] = {TNH * TNH, TNH, TNH * TNH, TNH};
   return vitmi_reduce_rows_segs(part, (int)(B * wpi), TH_PART, outs, widths, stream);
