@@ -1,6 +1,6 @@
 """Run bench.py with libvitmi debug switches set first (A/B of a kernel option inside the real step).
 usage: python tools/bench_with.py hook=value [hook=value ...] -- [bench.py args]
-e.g.   python tools/bench_with.py gemm_store_policy=0 gemm_band=0 -- --no-parity --no-alt --no-cpu-baseline"""
+e.g.   python tools/bench_with.py gemm_store_policy=0 gemm_band=0 -- --lean --no-cpu-baseline"""
 import ctypes
 import os
 import sys

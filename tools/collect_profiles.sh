@@ -2,7 +2,7 @@
 # usage (here, after tools/refresh_profiles.sh ran on the GPU box): tools/collect_profiles.sh [tag]
 # copies the judged summaries from gpurun_out/ (scratch) into profiles/ (tracked)
 set +e
-T=${1:-r03}
+T=${1:-r04}
 G=gpurun_out
 P=profiles
 cp $G/${T}_bench_n1*.json $P/
@@ -21,7 +21,7 @@ for c in cait_S24_224_bs256 swin_tiny_patch4_window7_224_bs256; do
 done
 cp $G/${T}_vitb_clock.txt $P/${T}_clock_two_methods.txt
 cp $G/${T}_hbm_rate_*.txt $P/
-cp $G/${T}_ab_round_switches.txt $P/
+cp $G/${T}_ab_*.txt $P/
 for a in cait_S24_224 swin_tiny_patch4_window7_224; do cp $G/${T}_${a}_pmc_traffic.txt $P/${T}_pmc_traffic_$a.txt; done
 cp $G/${T}_gemm_traffic_by_shape.txt $G/${T}_gemm_traffic_by_shape.json $P/
 ls $P | grep "^${T}_"

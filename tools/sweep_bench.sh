@@ -5,7 +5,7 @@ out=$1; shift
 : > $out
 for rnd in 1 2; do
   for h in "$@"; do
-    python tools/bench_with.py $h -- --no-parity --no-alt --no-cpu-baseline 2>/dev/null | python3 -c "
+    python tools/bench_with.py $h -- --lean --no-cpu-baseline --no-configs --no-dp-proxy --no-fp32-rate 2>/dev/null | python3 -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

@@ -1,5 +1,5 @@
 set -e
-A="--arch swin_tiny_patch4_window7_224 --batch 256 --no-parity --no-alt --no-cpu-baseline --graph off"
+A="--arch swin_tiny_patch4_window7_224 --batch 256 --lean --no-cpu-baseline --graph off"
 for r in 1 2; do
 for v in 0 1; do
 python tools/bench_with.py win_bwd_prefetch=$v -- $A 2>/dev/null | python3 -c "
