@@ -254,7 +254,7 @@ int vitmi_th_softmax_bwd(const void* S, const void* P, const void* dPm, const fl
  * score rows resident in LDS and both head mixes on the matrix pipe; the forward keeps nothing but O.  bf16, H = 8,
  * hd = 48, N <= 224, N % 4 == 0 (vitmi_th_attn_supported); other shapes / fp32 take the three-call form above.
  * qkv [B,N,3,H,hd], out / dout [B,N,H,hd].  The backward recomputes the scores and writes dqkv (all of it) and the four
- * proj_l / proj_w gradients (fp32, overwritten); dS and Pm ([B,H,N,ld] bf16, ld >= 224) are caller-owned SCRATCH through
+ * proj_l / proj_w gradients (fp32, overwritten); dS and Pm ([B,H,N,ld] bf16, ld >= 224, ld % 8 == 0, 16-B aligned) are caller-owned SCRATCH through
  * which dS and P' travel once between its two kernels (the row kernel and the dQ / dK / dV products).  workspace: vitmi_th_attn_workspace bytes, 256-B aligned. */
 int vitmi_th_attn_supported(int dtype, int64_t H, int64_t N, int64_t hd);
 size_t vitmi_th_attn_workspace(int64_t B, int64_t H, int64_t N, int64_t hd);

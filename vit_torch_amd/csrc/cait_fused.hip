@@ -789,8 +789,8 @@ extern "C" int vitmi_th_attn_bwd(const void* qkv, const void* dout, const float*
                                  void* workspace, size_t workspace_bytes, void* stream_) {
   VITMI_REQUIRE(qkv && dout && Wl && bl && Ww && bw && dqkv && dS && Pm && dWl && dbl && dWw && dbw && B > 0, VITMI_E_BADARG, "th_attn_bwd: null argument");
   VITMI_REQUIRE(vitmi_th_attn_supported(dtype, H, N, hd), VITMI_E_SHAPE, "th_attn_bwd: bf16, H = 8, hd = 48, N <= 224 and N %% 4 == 0 required");
-  VITMI_REQUIRE(ld >= NKP && ld % 4 == 0 && is_aligned(dS, 8) && is_aligned(Pm, 8) && is_aligned(qkv, 16) && is_aligned(dout, 16) && is_aligned(dqkv, 8),
-                VITMI_E_ALIGN, "th_attn_bwd: ld >= 224 (every key slot of a row is written), ld %% 4 == 0 and 8 / 16-byte aligned operands required");
+  VITMI_REQUIRE(ld >= NKP && ld % 8 == 0 && is_aligned(dS, 16) && is_aligned(Pm, 16) && is_aligned(qkv, 16) && is_aligned(dout, 16) && is_aligned(dqkv, 8),
+                VITMI_E_ALIGN, "th_attn_bwd: ld >= 224 (every key slot of a row is written), ld %% 8 == 0 (the products kernel reads 16-B row pieces), qkv / dout / dS / Pm 16-byte and dqkv 8-byte aligned");
   VITMI_REQUIRE(workspace && is_aligned(workspace, 256) && workspace_bytes >= vitmi_th_attn_workspace(B, H, N, hd), VITMI_E_WORKSPACE, "th_attn_bwd: workspace too small or misaligned");
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   char* rfK = reinterpret_cast<char*>(workspace);
