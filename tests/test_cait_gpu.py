@@ -73,7 +73,7 @@ def test_th_softmax_fwd_bwd(ops, th_grad_form, dt, B, H, N):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,H,N,hd", [(3, 4, 11, 12), (2, 8, 197, 48), (1, 2, 64, 64)])
+@pytest.mark.parametrize("B,H,N,hd", [(3, 4, 11, 12), (2, 8, 197, 48), (1, 2, 64, 64), (5, 12, 145, 64), (3, 8, 256, 48), (2, 3, 7, 32)])
 def test_class_attention_core(ops, dt, B, H, N, hd):
     rd = bf16_round if dt == torch.bfloat16 else (lambda t: t)
     D = H * hd

@@ -546,6 +546,191 @@ __global__ __launch_bounds__(256) void class_attn_bwd_kernel(const T* __restrict
   if (lane < hd) dq[b * H * hd + h * hd + lane] = from_f32<T>(acc * scale);
 }
 
+// ---- class attention, bf16 with hd % 8 == 0 (round 4): the kernels above walk a key row element by element (96 two-byte
+// loads and stores per lane and row: 127 / 248 us per cait_S24_224 layer for 77 MB of k / v).  Here EIGHT lanes share a key
+// row, lane & 7 = its 16-byte piece of the head's hd elements (pieces >= hd / 8 idle), lane >> 3 = one of 8 rows per step:
+// every access of k, v, dk, dv is a 16-byte piece of a contiguous hd x 2-byte run; a row's dot product is three xor-shuffles.
+constexpr int CA_STEPS = 64 * TH_MAXC / 8;         // 32 steps of 8 rows: N <= 256
+__device__ __forceinline__ void ca_fence() { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+__device__ __forceinline__ void ca_unpack(const bf16x8& v, float (&f)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
+}
+__device__ __forceinline__ float ca_row_sum(float a) {          // over the 8 lanes of a row
+  a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
+  return a;
+}
+__device__ __forceinline__ float ca_rows_sum(float a) {         // over the 8 rows of a step (same piece)
+  a += __shfl_xor(a, 8, 64); a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+  return a;
+}
+__global__ __launch_bounds__(256) void class_attn_fwd_vec_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
+                                                                const bf16* __restrict__ v, int64_t ts, bf16* __restrict__ out,
+                                                                float* __restrict__ psave, int64_t BH, int H, int N, int hd, float scale) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t bh = (int64_t)blockIdx.x * 4 + w;
+  if (bh >= BH) return;
+  const int64_t b = bh / H;
+  const int h = (int)(bh % H);
+  const int piece = lane & 7, rsub = lane >> 3;
+  const bool pok = piece * 8 < hd;
+  const int pc = pok ? piece : 0;                                // idle pieces read piece 0 and contribute zero
+  float qf[8];
+  ca_unpack(*reinterpret_cast<const bf16x8*>(q + b * H * hd + h * hd + pc * 8), qf);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) qf[e] = pok ? qf[e] * scale : 0.f;
+  const bf16* kb = k + b * N * ts + h * hd + pc * 8;
+  const bf16* vb = v + b * N * ts + h * hd + pc * 8;
+  // a batch = 8 steps whose 8 loads are issued together, unconditionally, from clamped rows (one round trip per batch: a
+  // branch around each load would cost one per step); whole batches beyond N are skipped (wave-uniform)
+  float sc[CA_STEPS], mx = -INFINITY;
+#pragma unroll
+  for (int s0 = 0; s0 < CA_STEPS; s0 += 8) {
+    ca_fence();                                                  // keep the batches apart (hipcc hoists all 32 loads otherwise)
+    bf16x8 raw[8];
+    if (s0 * 8 < N) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) raw[u] = *reinterpret_cast<const bf16x8*>(kb + (int64_t)min((s0 + u) * 8 + rsub, N - 1) * ts);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int s = s0 + u, j = s * 8 + rsub;
+      sc[s] = -INFINITY;
+      if (s0 * 8 < N) {
+        float kf[8];
+        ca_unpack(raw[u], kf);
+        float a = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a = fmaf(qf[e], kf[e], a);
+        a = ca_row_sum(a);
+        sc[s] = j < N ? a : -INFINITY;
+        mx = fmaxf(mx, sc[s]);
+      }
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 8, 64)); mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int s = 0; s < CA_STEPS; ++s) { sc[s] = expf(sc[s] - mx); sum += sc[s]; }     // exp(-inf) = 0 for the padding
+  sum = ca_rows_sum(sum);
+  const float rs = 1.f / sum;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int s0 = 0; s0 < CA_STEPS; s0 += 8) {
+    ca_fence();                                                  // keep the batches apart (hipcc hoists all 32 loads otherwise)
+    if (s0 * 8 < N) {
+      bf16x8 raw[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) raw[u] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)min((s0 + u) * 8 + rsub, N - 1) * ts);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int s = s0 + u, j = s * 8 + rsub;
+        const float p = sc[s] * rs;                                // 0 for j >= N
+        if (j < N && piece == 0) psave[bh * N + j] = p;
+        float vf[8];
+        ca_unpack(raw[u], vf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(p, vf[e], acc[e]);
+      }
+    }
+  }
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (bf16)ca_rows_sum(acc[e]);
+  if (rsub == 0 && pok) *reinterpret_cast<bf16x8*>(out + b * H * hd + h * hd + piece * 8) = o;
+}
+
+__global__ __launch_bounds__(256) void class_attn_bwd_vec_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
+                                                                const bf16* __restrict__ v, int64_t ts,
+                                                                const bf16* __restrict__ dout, const float* __restrict__ psave,
+                                                                bf16* __restrict__ dq, bf16* __restrict__ dk, bf16* __restrict__ dv,
+                                                                int64_t dts, int64_t BH, int H, int N, int hd, float scale) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t bh = (int64_t)blockIdx.x * 4 + w;
+  if (bh >= BH) return;
+  const int64_t b = bh / H;
+  const int h = (int)(bh % H);
+  const int piece = lane & 7, rsub = lane >> 3;
+  const bool pok = piece * 8 < hd;
+  const int pc = pok ? piece : 0;
+  float qf[8], dof[8];
+  ca_unpack(*reinterpret_cast<const bf16x8*>(q + b * H * hd + h * hd + pc * 8), qf);
+  ca_unpack(*reinterpret_cast<const bf16x8*>(dout + b * H * hd + h * hd + pc * 8), dof);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { qf[e] = pok ? qf[e] * scale : 0.f; dof[e] = pok ? dof[e] : 0.f; }
+  const bf16* kb = k + b * N * ts + h * hd + pc * 8;
+  const bf16* vb = v + b * N * ts + h * hd + pc * 8;
+  // dp_j = dout . v_j ; ds_j = p_j (dp_j - sum p dp)
+  float p[CA_STEPS], ds[CA_STEPS], dot = 0.f;
+#pragma unroll
+  for (int s0 = 0; s0 < CA_STEPS; s0 += 8) {
+    ca_fence();                                                  // keep the batches apart (hipcc hoists all 32 loads otherwise)
+    bf16x8 raw[8];
+    float pr[8];
+    if (s0 * 8 < N) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int jc = min((s0 + u) * 8 + rsub, N - 1);
+        raw[u] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)jc * ts);
+        pr[u] = psave[bh * N + jc];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int s = s0 + u, j = s * 8 + rsub;
+      p[s] = 0.f; ds[s] = 0.f;
+      if (s0 * 8 < N) {
+        float vf[8];
+        ca_unpack(raw[u], vf);
+        float a = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a = fmaf(dof[e], vf[e], a);
+        a = ca_row_sum(a);
+        p[s] = j < N ? pr[u] : 0.f;
+        ds[s] = a;
+        dot = fmaf(p[s], a, dot);
+      }
+    }
+  }
+  dot = ca_rows_sum(dot);                                        // every lane of a row carries the row's term once
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int s0 = 0; s0 < CA_STEPS; s0 += 8) {
+    ca_fence();                                                  // keep the batches apart (hipcc hoists all 32 loads otherwise)
+    if (s0 * 8 < N) {
+      bf16x8 raw[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) raw[u] = *reinterpret_cast<const bf16x8*>(kb + (int64_t)min((s0 + u) * 8 + rsub, N - 1) * ts);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int s = s0 + u, j = s * 8 + rsub;
+        const float d = p[s] * (ds[s] - dot);                    // 0 for j >= N
+        float kf[8];
+        ca_unpack(raw[u], kf);
+        bf16x8 ov, ok;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          ov[e] = (bf16)(p[s] * dof[e]);                         // dv_j = p_j dout
+          ok[e] = (bf16)(d * qf[e]);                             // dk_j = ds_j scale q   (qf carries the scale)
+          acc[e] = fmaf(d, kf[e], acc[e]);                       // dq = scale sum_j ds_j k_j
+        }
+        if (j < N && pok) {
+          *reinterpret_cast<bf16x8*>(dv + (b * N + j) * dts + h * hd + piece * 8) = ov;
+          *reinterpret_cast<bf16x8*>(dk + (b * N + j) * dts + h * hd + piece * 8) = ok;
+        }
+      }
+    }
+  }
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (bf16)(ca_rows_sum(acc[e]) * scale);
+  if (rsub == 0 && pok) *reinterpret_cast<bf16x8*>(dq + b * H * hd + h * hd + piece * 8) = o;
+}
+
 // ---- out[n] = sum_m x[m][n] * y[m][n]
 template <typename TX, typename TY>
 __global__ __launch_bounds__(256) void colsum_mul_partial_kernel(const TX* __restrict__ x, int64_t ldx,
@@ -647,7 +832,9 @@ extern "C" int vitmi_class_attn_fwd(const void* q, const void* k, const void* v,
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   const int64_t BH = B * H;
   dim3 grid((unsigned)((BH + 3) / 4));
-  if (dtype == VITMI_BF16)
+  if (dtype == VITMI_BF16 && hd % 8 == 0 && kv_token_stride % 8 == 0 && is_aligned(q, 16) && is_aligned(k, 16) && is_aligned(v, 16) && is_aligned(out, 16))
+    hipLaunchKernelGGL(class_attn_fwd_vec_kernel, grid, dim3(256), 0, stream, (const bf16*)q, (const bf16*)k, (const bf16*)v, kv_token_stride, (bf16*)out, p_save, BH, (int)H, (int)N, (int)hd, scale);
+  else if (dtype == VITMI_BF16)
     hipLaunchKernelGGL((class_attn_fwd_kernel<bf16>), grid, dim3(256), 0, stream, (const bf16*)q, (const bf16*)k, (const bf16*)v, kv_token_stride, (bf16*)out, p_save, BH, (int)H, (int)N, (int)hd, scale);
   else if (dtype == VITMI_F32)
     hipLaunchKernelGGL((class_attn_fwd_kernel<float>), grid, dim3(256), 0, stream, (const float*)q, (const float*)k, (const float*)v, kv_token_stride, (float*)out, p_save, BH, (int)H, (int)N, (int)hd, scale);
@@ -664,7 +851,10 @@ extern "C" int vitmi_class_attn_bwd(const void* q, const void* k, const void* v,
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   const int64_t BH = B * H;
   dim3 grid((unsigned)((BH + 3) / 4));
-  if (dtype == VITMI_BF16)
+  if (dtype == VITMI_BF16 && hd % 8 == 0 && kv_token_stride % 8 == 0 && dkv_token_stride % 8 == 0 && is_aligned(q, 16) && is_aligned(k, 16) &&
+      is_aligned(v, 16) && is_aligned(dout, 16) && is_aligned(dq, 16) && is_aligned(dk, 16) && is_aligned(dv, 16))
+    hipLaunchKernelGGL(class_attn_bwd_vec_kernel, grid, dim3(256), 0, stream, (const bf16*)q, (const bf16*)k, (const bf16*)v, kv_token_stride, (const bf16*)dout, p_save, (bf16*)dq, (bf16*)dk, (bf16*)dv, dkv_token_stride, BH, (int)H, (int)N, (int)hd, scale);
+  else if (dtype == VITMI_BF16)
     hipLaunchKernelGGL((class_attn_bwd_kernel<bf16>), grid, dim3(256), 0, stream, (const bf16*)q, (const bf16*)k, (const bf16*)v, kv_token_stride, (const bf16*)dout, p_save, (bf16*)dq, (bf16*)dk, (bf16*)dv, dkv_token_stride, BH, (int)H, (int)N, (int)hd, scale);
   else if (dtype == VITMI_F32)
     hipLaunchKernelGGL((class_attn_bwd_kernel<float>), grid, dim3(256), 0, stream, (const float*)q, (const float*)k, (const float*)v, kv_token_stride, (const float*)dout, p_save, (float*)dq, (float*)dk, (float*)dv, dkv_token_stride, BH, (int)H, (int)N, (int)hd, scale);
