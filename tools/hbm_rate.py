@@ -9,7 +9,7 @@ steps = (pm.get("_meta") or {}).get("steps_profiled")
 tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in pm.items() if k != "_meta")
 per_step = tot / steps
 ms = d["ms_per_step"]
-print(f"{d['config']['workload'][:60]}: {per_step / 1e9:.2f} GB of HBM traffic per step (PMC, {steps} steps profiled), "
+print(f"{d['config']['workload'].split(', 10 classes')[0]}: {per_step / 1e9:.2f} GB of HBM traffic per step (PMC, {steps} steps profiled), "
       f"{ms:.2f} ms/step -> {per_step / ms / 1e9:.2f} TB/s = {per_step / ms / 1e9 / peak:.3f} of the {peak:.0f} TB/s peak")
 top = sorted(((v["hbm_bytes_per_launch"] * v["launches"] / steps, k) for k, v in pm.items() if k != "_meta"), reverse=True)[:8]
 for b, k in top:
