@@ -27,6 +27,11 @@ def _debug_switches_back_to_defaults():
     part after `yield` runs on failures too) is undone before the next test starts."""
     yield
     from vit_torch_amd import _lib
-    if _lib.LIB_PATH.exists():
-        import ctypes
-        ctypes.CDLL(str(_lib.LIB_PATH)).vitmi_debug_reset()
+    # reset the library this process actually uses (the VITMI_LIB override included), and only if a test loaded it:
+    # a CPU-only run never dlopens the HIP .so from here
+    lib_ = getattr(_lib, "_lib", None)
+    if lib_ is not None:
+        try:
+            lib_.vitmi_debug_reset()
+        except (OSError, AttributeError):
+            pass

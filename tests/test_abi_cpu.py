@@ -165,3 +165,48 @@ def test_gemm_kernels_keep_their_accumulators_in_registers(lib):
     for name, r in kernels.items():
         assert int(r["ScratchSize [bytes/lane]"]) <= 192, (name, r["ScratchSize [bytes/lane]"])
         assert int(r["Occupancy [waves/SIMD]"]) >= 2, name
+
+
+# ------------------------------------------------------------------ libvitmi_comm.so (include/vitmi_comm.h) ---
+def _comm_declared():
+    text = open(os.path.join(ROOT, "include", "vitmi_comm.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vitmi_comm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_comm_library_exports_every_declared_symbol_and_binds_rccl():
+    """The gradient-exchange library: header <-> exports <-> ctypes table agree; RCCL is bound at run time from the copy
+    the process already has (PyTorch's), and reports its version.  No communicator is created without a GPU."""
+    import ctypes
+    from vit_torch_amd import build, comm
+    if not comm.LIB_PATH.exists():
+        build.build_comm()
+    declared = _comm_declared()
+    assert len(declared) >= 10
+    assert sorted(comm.SIGNATURES) == declared
+    raw = ctypes.CDLL(str(comm.LIB_PATH))
+    for name in declared:
+        assert hasattr(raw, name), f"libvitmi_comm.so does not export {name}"
+    lib = comm.load()
+    assert lib.vitmi_comm_version() == 1
+    v = comm.rccl_version()
+    assert 20000 <= v < 30000, v
+    # calls on a null communicator are refused with a message, not a crash
+    assert lib.vitmi_comm_join(None, None) == -1 and b"null communicator" in lib.vitmi_comm_last_error()
+    assert lib.vitmi_comm_allreduce_sum_f32_async(None, None, 0, None) == -1
+
+
+def test_comm_library_is_not_linked_against_a_second_rccl():
+    """libvitmi_comm.so must not carry a DT_NEEDED on librccl: a second copy beside PyTorch's would own a second set of
+    device-side state.  (readelf is part of binutils; skip if it is not there.)"""
+    import shutil
+    import subprocess
+    from vit_torch_amd import build, comm
+    if shutil.which("readelf") is None:
+        import pytest
+        pytest.skip("readelf not installed")
+    if not comm.LIB_PATH.exists():
+        build.build_comm()
+    out = subprocess.run(["readelf", "-d", str(comm.LIB_PATH)], capture_output=True, text=True).stdout
+    needed = re.findall(r"\(NEEDED\)\s+Shared library: \[(.*?)\]", out)
+    assert needed and not any("rccl" in n or "nccl" in n for n in needed), needed

@@ -90,3 +90,77 @@ def test_world1_reducer_is_a_noop():
     red.section_ready(list(lin.parameters()))
     red.finish()
     assert red.launched == []
+
+
+# ------------------------------------------------------------------ Network(ddp=...) : SURVEY §8(e) in the library ---
+def _fit_data():
+    g = torch.Generator("cpu").manual_seed(3)
+    train = [(torch.randn(8, 3, 16, 16, generator=g), torch.randint(0, 10, (8,), generator=g)) for _ in range(3)]
+    val = [(torch.randn(8, 3, 16, 16, generator=g), torch.randint(0, 10, (8,), generator=g)) for _ in range(2)]
+    return train, val
+
+
+def _fit_model(seed):
+    from oracle import vit_ref
+    cfg = dict(img_size=16, patch_size=8, embed_dim=32, depth=2, num_heads=2)
+    model = vit_ref.VisionTransformer(**cfg, apply_head=True)
+    model.head = vit_ref.get_classifier_head(32, 10)
+    vit_ref.seeded_init_(model, seed)
+    return model
+
+
+def _fit_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vit_torch_amd.network import Network
+    train, val = _fit_data()
+    # every rank starts from DIFFERENT weights: the broadcast from rank 0 must make them equal
+    net = Network(_fit_model(1 + rank), opt="torch_sgd", loss_fn=torch.nn.CrossEntropyLoss(), lr=0.05, lr_type="step",
+                  lr_step=1, lr_gamma=0.5, device="cpu", ddp={"size": world, "rank": rank})
+    hist = net.fit(net.shard(train), net.shard(val), epochs=2)
+    out = {"rank": rank, "buckets": len(net.reducer.launched),
+           "train": [(h["train"]["loss_avg"], h["train"]["acc"], h["train"]["samples_global"]) for h in hist],
+           "val": [(h["val"]["loss_avg"], h["val"]["acc"]) for h in hist],
+           "local_losses": [h["train"]["loss"] for h in hist],
+           "params": {n: p.detach().numpy().copy() for n, p in net.model.named_parameters()}}      # numpy: pickled by value
+    q.put(out)
+    dist.destroy_process_group()
+
+
+def test_network_fit_world2_gloo_equals_one_process_on_the_global_batches():
+    """Two ranks, each on its half of every global batch (ShardedLoader), rank 1 starting from other weights: after two
+    `Network.fit` epochs the parameters, the epoch losses and accuracies equal a single-process run on the whole batches
+    (mean cross-entropy over the global batch = mean of the two half-batch means; gradients averaged by the reducer);
+    loss and accuracy reach the ranks through ONE 2-float all-reduce per epoch."""
+    sys.path.insert(0, ROOT)
+    from vit_torch_amd.network import Network
+    train, val = _fit_data()
+    ref = Network(_fit_model(1), opt="torch_sgd", loss_fn=torch.nn.CrossEntropyLoss(), lr=0.05, lr_type="step", lr_step=1,
+                  lr_gamma=0.5, device="cpu")
+    want = ref.fit(train, val, epochs=2)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_fit_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in procs), key=lambda r: r["rank"])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res:
+        assert r["buckets"] >= 1
+        for e in range(2):
+            loss, acc, n = r["train"][e]
+            assert n == 24
+            assert abs(loss - want[e]["train"]["loss_avg"]) < 2e-5, (r["rank"], e, loss, want[e]["train"]["loss_avg"])
+            assert abs(acc - want[e]["train"]["acc"]) < 1e-9
+            assert abs(r["val"][e][0] - want[e]["val"]["loss_avg"]) < 2e-5
+            assert abs(r["val"][e][1] - want[e]["val"]["acc"]) < 1e-9
+        for n, p in ref.model.named_parameters():
+            d = (torch.from_numpy(r["params"][n]) - p.detach()).abs().max().item() / (p.detach().abs().max().item() + 1e-12)
+            assert d < 2e-5, f"rank {r['rank']}: {n} differs from the one-process run by {d}"
+    # the two ranks' local losses differ (they see different halves) while the all-reduced epoch figures agree
+    assert res[0]["local_losses"] != res[1]["local_losses"]
+    assert res[0]["train"] == res[1]["train"] and res[0]["val"] == res[1]["val"]

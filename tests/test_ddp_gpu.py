@@ -229,3 +229,158 @@ def test_bench_two_rank_line_on_one_gpu_over_gloo():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 128
     assert d["value"] > 0 and d["roofline"] is not None and d["config"]["hip_graph"] is False
+
+
+# ---- SURVEY §8(e) in the library: Network(ddp={'size', 'rank'}) ---------------------------------------------------------
+def _net_data(n_batches=3, bs=128):
+    g = torch.Generator("cpu").manual_seed(21)
+    return [(torch.randn(bs, 3, 32, 32, generator=g), torch.randint(0, 10, (bs,), generator=g)) for _ in range(n_batches)]
+
+
+def _net_model(seed, compute="bf16"):
+    from vit_torch_amd import VisionTransformer
+    torch.manual_seed(seed)
+    m = VisionTransformer(img_size=32, patch_size=16, embed_dim=128, depth=3, num_heads=2, num_classes=10,
+                          compute_dtype=compute, residual_dtype="auto")
+    m.head = torch.nn.Linear(128, 10, bias=False)
+    m.apply_head = True
+    return m
+
+
+def test_network_with_ddp_in_a_world_of_one_equals_the_plain_network(nccl_world_of_one, lib):
+    """`Network(..., ddp={'size': 1, 'rank': 0, 'force': True})` on RCCL: reducer on the engine, parameters broadcast, the
+    optimizer's grad_scale 1 / world, the epoch's 2-float all-reduce — the same two epochs as without `ddp`, bit for bit."""
+    from vit_torch_amd.network import Network
+    train, val = _net_data(), _net_data(2)
+    plain = Network(_net_model(7), opt="sgd", lr=0.02, lr_step=1, device="cuda")
+    want = plain.fit(train, val, epochs=2)
+    net = Network(_net_model(7), opt="sgd", lr=0.02, lr_step=1, device="cuda", ddp={"size": 1, "rank": 0, "force": True})
+    assert net.model.engine().reducer is net.reducer and net.optimizer.param_groups[0]["grad_scale"] == 1.0
+    got = net.fit(net.shard(train), net.shard(val), epochs=2)
+    assert len(net.reducer.launched) >= 2 * len(train)
+    for w, g in zip(want, got):
+        assert g["train"]["loss"] == w["train"]["loss"] and g["val"]["loss"] == w["val"]["loss"]
+        assert g["train"]["loss_avg"] == pytest.approx(w["train"]["loss_avg"], rel=1e-6)
+        assert g["train"]["acc"] == pytest.approx(w["train"]["acc"]) and g["val"]["acc"] == pytest.approx(w["val"]["acc"])
+        assert g["train"]["samples_global"] == 3 * 128
+    assert torch.equal(net.model.engine().pack.flat, plain.model.engine().pack.flat)
+
+
+def _two_rank_network_worker(rank, world, port, outdir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vit_torch_amd.network import Network
+    torch.cuda.set_device(0)
+    net = Network(_net_model(50 + rank, "fp32"), opt="sgd", lr=0.02, lr_step=1, device="cuda", ddp={"size": world, "rank": rank})
+    hist = net.fit(net.shard(_net_data()), net.shard(_net_data(2)), epochs=2)
+    torch.cuda.synchronize()
+    torch.save((net.model.engine().pack.flat.detach().cpu(), [(h["train"]["loss_avg"], h["train"]["acc"], h["val"]["loss_avg"],
+                                                               h["val"]["acc"]) for h in hist]), os.path.join(outdir, f"net{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_network_fit_two_ranks_on_one_gpu_match_the_global_batch_run(lib, tmp_path):
+    """Two processes on the one GPU (gloo between them), each `Network.fit` on its half of every global batch through the
+    HIP engine in fp32 mode; rank 1 starts from other weights.  Parameters and epoch figures equal the single-process run
+    on the whole batches."""
+    import torch.multiprocessing as mp
+    from vit_torch_amd.network import Network
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_two_rank_network_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    got = [torch.load(tmp_path / f"net{r}.pt") for r in range(2)]
+    assert torch.equal(got[0][0], got[1][0]) and got[0][1] == got[1][1]
+    ref = Network(_net_model(50, "fp32"), opt="sgd", lr=0.02, lr_step=1, device="cuda")
+    want = ref.fit(_net_data(), _net_data(2), epochs=2)
+    flat = ref.model.engine().pack.flat.detach().cpu()
+    assert (got[0][0] - flat).norm() / flat.norm() < 5e-6
+    for e in range(2):
+        tl, ta, vl, va = got[0][1][e]
+        assert tl == pytest.approx(want[e]["train"]["loss_avg"], rel=2e-5) and vl == pytest.approx(want[e]["val"]["loss_avg"], rel=2e-5)
+        assert ta == pytest.approx(want[e]["train"]["acc"], abs=1e-9) and va == pytest.approx(want[e]["val"]["acc"], abs=1e-9)
+
+
+# ---- libvitmi_comm.so: the own RCCL communicator ------------------------------------------------------------------------
+def test_own_rccl_communicator_in_a_world_of_one(nccl_world_of_one, lib):
+    """ncclCommInitRank through libvitmi_comm (RCCL bound from the copy PyTorch loaded), what RCCL reports about the
+    communicator, the async bucket exchange ordered against the compute stream, join, broadcast, the metric all-reduce."""
+    from vit_torch_amd import comm
+    c = comm.default_comm()
+    assert comm.default_comm() is c, "one communicator per process"
+    info = c.info()
+    assert info["comm_ranks"] == 1 and info["comm_rank"] == 0 and info["comm_device"] == torch.cuda.current_device()
+    assert 20000 <= info["rccl_version"] < 30000
+    buf = torch.arange(1 << 20, dtype=torch.float32, device="cuda")
+    want = buf * 2 + 1
+    buf.mul_(2)                                   # queued on the compute stream BEFORE the exchange: must be seen by it
+    c.allreduce_async(buf)                        # identity over one rank, on the comm stream
+    c.join()
+    buf.add_(1)                                   # after the join: ordered behind the exchange
+    torch.cuda.synchronize()
+    assert torch.equal(buf, want)
+    c.broadcast(buf, 0)
+    small = torch.tensor([3.5, 2.0], device="cuda")
+    c.allreduce(small)
+    torch.cuda.synchronize()
+    assert small.tolist() == [3.5, 2.0] and torch.equal(buf, want)
+    with pytest.raises(Exception, match="fp32"):
+        c.allreduce_async(buf.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("transport", ["rccl", "pg"])
+def test_both_transports_leave_the_step_unchanged(nccl_world_of_one, lib, transport):
+    from vit_torch_amd import CrossEntropyLoss, FusedSGD, VisionTransformer
+    from vit_torch_amd.ddp import GradReducer
+
+    def run(tr):
+        torch.manual_seed(3)
+        m = VisionTransformer(img_size=32, patch_size=16, embed_dim=128, depth=3, num_heads=2, num_classes=10,
+                              compute_dtype="bf16", residual_dtype="auto").cuda()
+        m.head = torch.nn.Linear(128, 10, bias=False).cuda()
+        eng = m.engine()
+        red = None
+        if tr is not None:
+            red = eng.reducer = GradReducer(eng.pack, min_bucket_elems=1 << 16, force=True, transport=tr)
+            red.broadcast_parameters(0)
+        opt = FusedSGD(m.parameters(), lr=1e-2, momentum=0.9)
+        g = torch.Generator("cpu").manual_seed(0)
+        x, y = torch.randn(64, 3, 32, 32, generator=g).cuda(), torch.randint(0, 10, (64,), generator=g).cuda()
+        for _ in range(3):
+            opt.zero_grad(); CrossEntropyLoss()(m(x), y).backward(); opt.step()
+        torch.cuda.synchronize()
+        return eng.pack.flat.clone(), red
+
+    p0, _ = run(None)
+    p1, red = run(transport)
+    assert (red.comm is not None) == (transport == "rccl") and len(red.launched) >= 6
+    assert red.transport_info()["transport"].startswith("libvitmi_comm" if transport == "rccl" else "torch.distributed")
+    assert torch.equal(p0, p1)
+
+
+def test_shared_device_flag_only_on_the_launches_right_after_a_bucket(nccl_world_of_one, lib):
+    """VITMI_LAUNCH_SHARED_DEVICE on the `shared_launches` launches after each bucket's flush, not on
+    every launch from the first bucket to finish()."""
+    from vit_torch_amd._lib import LAUNCH_SHARED_DEVICE
+    from vit_torch_amd.ddp import GradReducer
+    from vit_torch_amd.packing import ParamPack
+    lin = torch.nn.Linear(1024, 1024).cuda()
+    pack = ParamPack(list(lin.named_parameters()), "cuda", shadow=False)
+    red = GradReducer(pack, min_bucket_elems=1, force=True)
+    assert red.launch_flags() == 0                               # nothing in flight yet
+    red.section_ready([lin.bias])
+    flags = [red.launch_flags() for _ in range(red.shared_launches + 2)]
+    assert flags == [LAUNCH_SHARED_DEVICE] * red.shared_launches + [0, 0]
+    red.section_ready([lin.weight])
+    assert red.launch_flags() == LAUNCH_SHARED_DEVICE            # a new bucket re-arms it
+    red.finish()
+    assert red.launch_flags() == 0
+    torch.cuda.synchronize()

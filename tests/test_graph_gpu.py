@@ -124,3 +124,92 @@ def test_graph_without_the_weight_cast_follows_weights_changed_between_replays(l
     m3, crit3, _ = _make()
     stock = torch.optim.SGD(m3.parameters(), lr=5e-2, momentum=0.9)
     assert GraphedStep(m3, crit3, stock, *data[0], warmup=1)._pack is None
+
+
+# ---- round 5: the capture contract that came out of round 4's two crashes -----------------------------------
+def _small_step(seed=5, **kw):
+    from vit_torch_amd import CrossEntropyLoss, FusedSGD, VisionTransformer
+    torch.manual_seed(seed)
+    m = VisionTransformer(img_size=32, patch_size=16, embed_dim=128, depth=2, num_heads=2, num_classes=10,
+                          compute_dtype="bf16", residual_dtype="auto", **kw).cuda()
+    m.head = torch.nn.Linear(128, 10, bias=False).cuda()
+    m.engine()
+    g = torch.Generator("cpu").manual_seed(0)
+    x, y = torch.randn(32, 3, 32, 32, generator=g).cuda(), torch.randint(0, 10, (32,), generator=g).cuda()
+    return m, CrossEntropyLoss(), FusedSGD(m.parameters(), lr=1e-2, momentum=0.9), x, y
+
+
+def test_a_second_graphed_step_on_a_live_engine_is_refused_and_close_releases_it():
+    """Two captured steps over ONE engine share its flat buffers, optimizer state and cached tables; round 4's capture_end
+    segfault sat on a second GraphedStep beside a live first.  The second is refused with a VitmiError; after close() (or
+    when the first is garbage) the engine can be captured again, and the new graph's replay equals the eager step."""
+    from vit_torch_amd import GraphedStep
+    from vit_torch_amd._lib import VitmiError
+    m, crit, opt, x, y = _small_step()
+    gs = GraphedStep(m, crit, opt, x, y)
+    with pytest.raises(VitmiError, match="live GraphedStep"):
+        GraphedStep(m, crit, opt, x, y)
+    l1 = float(gs(x, y).item())                    # the refused construction left the first graph usable
+    gs.close()
+    assert gs.graph is None
+    gs2 = GraphedStep(m, crit, opt, x, y, warmup=0)      # everything is initialised: no warm-up needed on the same engine
+    l2 = float(gs2(x, y).item())
+    assert l1 == l1 and l2 == l2 and l2 < l1 + 1.0
+    # same weights, one eager step and one replayed step: the same loss
+    m3, crit3, opt3, _, _ = _small_step()
+    m3.load_state_dict(m.state_dict())
+    opt3.zero_grad(); want = crit3(m3(x), y); want.backward(); opt3.step()
+    got = gs2(x, y)
+    assert float(got.item()) == pytest.approx(float(want.item()), rel=2e-3)
+
+
+def test_recapture_after_the_engine_was_rebuilt_warms_up_eagerly_first():
+    """A model whose configuration moved since the capture gets a NEW engine (new flat buffers, lazily built tables).
+    `recapture()` with warmup = 0 must not run that engine's first step inside the capture (lazy initialisation there is
+    illegal, raises, and the capture_end behind an invalidated capture is where round 4 crashed): it resolves the engine
+    eagerly, sees that it is not the one the graph was captured on, and runs one eager step first."""
+    from vit_torch_amd import GraphedStep
+    m, crit, opt, x, y = _small_step()
+    gs = GraphedStep(m, crit, opt, x, y)
+    eng0 = gs._engine
+    m.cls_only_last_block = True                   # a configuration change: engine().is_current() turns false
+    gs.warm_loss = None
+    gs.recapture()                                 # warmup = 0 asked for
+    assert gs._engine is not eng0 and gs._engine is m.engine()
+    assert gs.warm_loss is not None, "the rebuilt engine's first step must have run eagerly"
+    l = float(gs(x, y).item())
+    assert l == l
+
+
+def test_capture_tolerates_hip_calls_from_another_thread():
+    """thread_local capture mode: a helper thread (ProcessGroupNCCL's watchdog polling hipEventQuery, a pin-memory thread)
+    may call into HIP while the step is being captured.  A thread hammers event queries and allocations during the
+    capture; under the default global mode these invalidate the capture."""
+    import threading
+    from vit_torch_amd import GraphedStep
+    m, crit, opt, x, y = _small_step()
+    ev = torch.cuda.Event()
+    ev.record()
+    torch.cuda.synchronize()
+    stop = threading.Event()
+    errors = []
+
+    def poll():
+        try:
+            import time
+            while not stop.is_set():
+                ev.query()                          # hipEventQuery from another thread
+                time.sleep(0.0005)
+        except Exception as e:                      # pragma: no cover
+            errors.append(e)
+
+    t = threading.Thread(target=poll, daemon=True)
+    t.start()
+    try:
+        gs = GraphedStep(m, crit, opt, x, y)
+    finally:
+        stop.set()
+        t.join()
+    assert not errors, errors
+    l = float(gs(x, y).item())
+    assert l == l and abs(l) < 1e3

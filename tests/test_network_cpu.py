@@ -93,3 +93,64 @@ def test_bench_refuses_a_traffic_file_from_other_kernel_sources(tmp_path):
     assert 'meta.get("kernel_sources_sha256") != kernel_sources_sha256()' in src and "refused, traffic = null" in src
     tool = open(os.path.join(root, "tools", "pmc_traffic.py")).read()
     assert "kernel_sources_sha256" in tool
+
+
+# ------------------------------------------------------------------ early stopping (utils_network.py:322-328) ---
+def _scripted_network(val_accs):
+    """A Network over a tiny CPU module whose epochs return scripted validation accuracies."""
+    from vit_torch_amd.network import Network
+
+    class Scripted(Network):
+        def __init__(self):
+            super().__init__(torch.nn.Linear(4, 2), opt="torch_sgd", loss_fn=torch.nn.CrossEntropyLoss(), device="cpu",
+                             epochs=len(val_accs), earlystop_epoch=3)
+            self.calls = []
+
+        def run_one_epoch(self, dataloader, training=True):
+            self.calls.append("train" if training else "val")
+            n_val = sum(1 for c in self.calls if c == "val")
+            acc = 0.1 if training else val_accs[n_val - 1]
+            return {"loss": [1.0], "loss_avg": 1.0, "correct": np.zeros(4, dtype=bool), "acc": acc}
+
+    return Scripted()
+
+
+def test_fit_stops_early_like_the_reference():
+    """After a validation round: once `earlystop_epoch` accuracies exist, stop if none of the last `earlystop_epoch` reaches
+    the best so far; the stop takes effect at the top of the NEXT epoch (utils_network.py:256-259, 322-328)."""
+    accs = [0.50, 0.60, 0.55, 0.50, 0.65, 0.70]
+    net = _scripted_network(accs)
+    hist = net.fit([None], [None], earlystop_epoch=2)
+    # after epoch 3 the last two are (0.55, 0.50) < best 0.60 -> epoch 4 does not run
+    assert len(hist) == 4 and net.stopped_early_after == 4
+    assert net.calls == ["train", "val"] * 4
+    # a window that still holds the best never stops
+    net = _scripted_network(accs)
+    assert len(net.fit([None], [None], earlystop_epoch=3)) == 6 and net.stopped_early_after is None
+    # the reference's quirk: the constructor's earlystop_epoch (3 here) is ignored, fit()'s own default of 10 rules
+    net = _scripted_network([0.9] + [0.1] * 11)
+    hist = net.fit([None], [None])
+    assert len(hist) == 11 and net.stopped_early_after == 11       # accs 1..10 (ten of them) < 0.9 after epoch 10
+    # earlystop_epoch = 0: the window is the whole history, which always holds the best
+    net = _scripted_network([0.9, 0.1, 0.1, 0.1])
+    assert len(net.fit([None], [None], earlystop_epoch=0)) == 4
+    # no validation loader: nothing to stop on
+    net = _scripted_network([0.9, 0.1, 0.1, 0.1])
+    assert len(net.fit([None], None, earlystop_epoch=1)) == 4
+
+
+def test_sharded_loader_splits_rows_and_refuses_uneven_batches():
+    from vit_torch_amd.network import ShardedLoader
+    x, y = torch.arange(24.).view(8, 3), torch.arange(8)
+    parts = [list(ShardedLoader([(x, y)], r, 4)) for r in range(4)]
+    assert torch.equal(torch.cat([p[0][1] for p in parts]), y)
+    assert torch.equal(parts[2][0][0], x[4:6])
+    with pytest.raises(ValueError):
+        list(ShardedLoader([(x[:6], y[:6])], 0, 4))
+
+
+def test_network_ddp_needs_a_process_group():
+    from vit_torch_amd.network import Network
+    with pytest.raises(ValueError, match="process group"):
+        Network(torch.nn.Linear(4, 2), opt="torch_sgd", loss_fn=torch.nn.CrossEntropyLoss(), device="cpu",
+                ddp={"size": 2, "rank": 0})

@@ -1167,3 +1167,25 @@ def test_gemm_ragged_m_runs_on_the_tile_kernel_with_padded_rows(ops, layout, epi
             kw0[key] = kw0[key].contiguous().clone() if key != "C2" else torch.empty((M, N), device="cuda", dtype=bt)
     ops.gemm(A, Bm, C0, **kw0)
     assert_close("tile kernel vs ragged kernel", C, C0.float().cpu(), 8e-3)
+
+
+def test_gemm_ragged_m_fp32_output_never_splits_k(ops):
+    """an fp32-C plain-store launch with VITMI_LAUNCH_ROWS_PADDED whose tile count invites split-K
+    (nn, M = 6304 = 24.6 row tiles x 3 column tiles = 75 tiles <= 128, K = 1536 = 24 k-steps) used to stride the k-slices by
+    M rows while the ragged last row tile stored whole 256-row tiles: the padding rows of slice s landed on the first rows of
+    slice s + 1 and the last slice wrote beyond the workspace.  Ragged M now never splits K: the first rows must equal the
+    fp32 reference and nothing behind the padded C may be touched."""
+    from vit_torch_amd._lib import LAUNCH_ROWS_PADDED
+    M, N, K = 6304, 768, 1536
+    bt = torch.bfloat16
+    Mp = (M + 255) // 256 * 256
+    a, b = bf16_round(gen((M, K), 11)), bf16_round(gen((N, K), 12) * 0.2)
+    A = dev(a).to(bt)
+    Bt = dev(b.t().contiguous()).to(bt)
+    guard = 64
+    cbuf = torch.full((Mp + guard, N), float("nan"), device="cuda")
+    C = cbuf[:M]
+    ops.gemm(A, Bt, C, b_kmajor=False, launch_flags=LAUNCH_ROWS_PADDED)
+    torch.cuda.synchronize()
+    assert_close("ragged nn fp32", C, a @ b.t(), 1e-4)
+    assert torch.isnan(cbuf[Mp:]).all(), "rows beyond the padding were written"

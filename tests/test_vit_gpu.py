@@ -394,3 +394,48 @@ def test_cls_only_last_block_gives_the_same_step(compute, residual):
         for (n, pr) in ref.named_parameters():
             if pr.grad is not None and pr.grad.abs().max().item() > 1e-9:
                 assert_close(f"grad[{n}] vs oracle", res[1][2][n], pr.grad, 3e-4)
+
+
+def test_cls_only_last_block_at_tile_kernel_width():
+    """the CLS-only last block at embed_dim 768 and a batch whose M = 197 B is ragged (B = 16: 3 152 rows) — the
+    d ln1 = dkv Wkv product is an fp32-output launch on the 256x256 tile kernel with padded rows, the shape that used to
+    split K over a workspace strided by M.  Same step as the full computation."""
+    from vit_torch_amd import CrossEntropyLoss, VisionTransformer, VisionModelZoo
+    cfg = dict(img_size=224, patch_size=16, in_chans=3, embed_dim=768, depth=2, num_heads=12)
+    ref, full = make_pair(cfg, 10, "bf16", "bf16")
+    x, y = data(16, 3, 224, 10, seed=11)
+    m = VisionTransformer(**cfg, apply_head=True, compute_dtype="bf16", residual_dtype="bf16", cls_only_last_block=True)
+    m.head = VisionModelZoo.get_classifier_head(cfg["embed_dim"], 10)
+    m.load_state_dict(ref.state_dict(), strict=True)
+    m = m.cuda()
+    crit = CrossEntropyLoss()
+    res = []
+    for mod in (full, m):
+        out = mod(x.cuda())
+        loss = crit(out, y.cuda())
+        mod.zero_grad()
+        loss.backward()
+        res.append((out.detach().float().cpu(), {n: p.grad.detach().float().cpu() for n, p in mod.named_parameters()}))
+    assert m.engine().cls_last
+    assert_close("logits", res[1][0], res[0][0], 8e-3)
+    gmax = max(g.norm().item() for g in res[0][1].values())
+    for n, g0 in res[0][1].items():
+        g1 = res[1][1][n]
+        if g0.norm().item() < 1e-6 * gmax:
+            assert g1.norm().item() < 1e-4 * gmax, n
+            continue
+        assert_close(f"grad[{n}]", g1, g0, 4e-2)
+
+
+def test_cls_only_last_block_refuses_shapes_its_kernel_cannot_run():
+    """The class-attention kernels take hd <= 64 and N <= 256: a head dimension beyond that is refused when the engine is
+    built, a longer sequence (dino_vitb8 at 224 x 224: N = 785) before the first kernel of the forward is launched."""
+    from vit_torch_amd import VisionTransformer
+    from vit_torch_amd._lib import VitmiError
+    m = VisionTransformer(img_size=32, patch_size=8, embed_dim=256, depth=1, num_heads=2, cls_only_last_block=True).cuda()
+    with pytest.raises(VitmiError, match="cls_only_last_block"):
+        m.engine()
+    m = VisionTransformer(img_size=224, patch_size=8, embed_dim=128, depth=1, num_heads=2, cls_only_last_block=True).cuda()
+    with pytest.raises(VitmiError, match="cls_only_last_block"):
+        m(torch.randn(1, 3, 224, 224, device="cuda"))
+    m(torch.randn(2, 3, 96, 96, device="cuda"))          # N = 145: fine

@@ -18,6 +18,8 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OBJ = CSRC / "_obj"
 LIB = HERE / "libvitmi.so"
+COMM_LIB = HERE / "libvitmi_comm.so"      # the RCCL gradient exchange (include/vitmi_comm.h): host code only, RCCL bound at run time
+COMM_SRC = "comm.cpp"
 ARCH = "gfx950"
 
 SOURCES = [
@@ -113,9 +115,26 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")
+    build_comm(force)
     if verbose:
-        print(f"built {LIB} ({LIB.stat().st_size} bytes)")
+        print(f"built {LIB} ({LIB.stat().st_size} bytes), {COMM_LIB} ({COMM_LIB.stat().st_size} bytes)")
     return LIB
+
+
+def build_comm(force: bool = False) -> Path:
+    """libvitmi_comm.so: one host source; links libamdhip64 (through hipcc) and libdl, NOT librccl — the RCCL entry points
+    are bound with dlopen / dlsym from the copy the process has already loaded (vitmi_comm_load)."""
+    src = CSRC / COMM_SRC
+    hdr = (CSRC / "../../include/vitmi_comm.h").resolve()
+    stamp = max(src.stat().st_mtime, hdr.stat().st_mtime, Path(__file__).stat().st_mtime)
+    if not force and COMM_LIB.exists() and COMM_LIB.stat().st_mtime >= stamp:
+        return COMM_LIB
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O2", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
+           "-Wno-unused-command-line-argument", "-x", "hip", str(src), "-o", str(COMM_LIB), "-ldl"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on {COMM_SRC}:\n{r.stderr}")
+    return COMM_LIB
 
 
 if __name__ == "__main__":

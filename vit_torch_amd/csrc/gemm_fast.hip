@@ -1270,7 +1270,9 @@ int launch_p(const GemmArgs& g_in, hipStream_t stream) {
   if constexpr (MODE == VITMI_EPI_STORE && sizeof(TC) == 4) {
     int splits, ksps;
     splitk_plan(nwg, (int)(g.K / BK), &splits, &ksps);
-    if (splits > 1 && g.ws && g.ws_bytes >= (size_t)splits * g.M * g.N * sizeof(float)) {
+    // (a ragged last row tile stores WHOLE 256-row tiles: with the slices strided by M rows its padding rows would land on
+    // the first rows of the next slice and, for the last slice, beyond the workspace — ragged M never splits K)
+    if (splits > 1 && (g.M % BM) == 0 && g.ws && g.ws_bytes >= (size_t)splits * g.M * g.N * sizeof(float)) {
       auto kern = gemm_fast_kernel<A_KM, B_KM, MODE, TC, true, PIPE>;
       if (int rc = vitmi_raise_dynamic_lds(reinterpret_cast<const void*>(kern), 2 * STAGE_BYTES, "gemm_fast(split-K)")) return rc;
       float* ws = reinterpret_cast<float*>(g.ws);
@@ -1438,7 +1440,7 @@ size_t gemm_fast_workspace(const GemmArgs& g) {
   if (use_tile2(g)) return gemm_fast2_workspace(g);
   const int tiles = (int)((g.M + BM - 1) / BM * (g.N / BN));
   size_t need = 0;
-  if (g.e.mode == VITMI_EPI_STORE && !g.e.c_bf16) {
+  if (g.e.mode == VITMI_EPI_STORE && !g.e.c_bf16 && (g.M % BM) == 0) {
     int splits, ksps;
     splitk_plan(tiles, (int)(g.K / BK), &splits, &ksps);
     if (splits > 1) need = (size_t)splits * g.M * g.N * sizeof(float);

@@ -12,6 +12,14 @@ i-1.. .  `finish()` makes the compute stream wait for every bucket; the SUM is
 turned into the mean by the optimizer's `grad_scale = 1/world` (one fewer pass
 over the gradients).  xGMI is point-to-point, so buckets are kept large
 (one transformer block = 28 MB fp32 for ViT-B) rather than many small ones.
+
+Transport (round 5).  On the GPU with torch.distributed's backend "nccl" the buckets go through the library's OWN RCCL
+communicator (`comm.RcclComm`, libvitmi_comm.so: `ncclAllReduce` on a dedicated HIP stream, two events, no helper
+thread).  Until round 4 they rode ProcessGroupNCCL, whose watchdog thread aborted the process beside a
+HIP-graph capture of the step (a `hipEventQuery` on an event last recorded in a capturing stream); with the own
+communicator no thread but the caller's ever touches the exchange's events, eager or captured.  ProcessGroup
+collectives remain for what cannot run on RCCL: CPU tensors / the gloo backend (the world-2 tests), or
+`VITMI_COMM=pg` (A/B against the old transport).
 """
 from __future__ import annotations
 
@@ -22,22 +30,43 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, pack, group=None, min_bucket_elems: int = 4 << 20, force: bool = False):
+    def __init__(self, pack, group=None, min_bucket_elems: int = 4 << 20, force: bool = False, transport: str = "auto"):
         """force: exchange even in a world of one (exercises the RCCL stream ordering on a
-        single GPU; tests only)."""
+        single GPU; tests only).  transport: "auto" (own RCCL communicator for GPU buffers under the "nccl" backend,
+        else the process group), "rccl", or "pg"."""
+        import os
         self.pack = pack
         self.group = group
         self.force = bool(force)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        # RCCL's all-reduce kernels hold a few dozen CUs while a bucket is in flight, and a 256x256-tile
-        # GEMM / attention-backward workgroup needs a whole CU: with the persistent grids (a FIXED list of
-        # tiles / pairs per workgroup) the workgroups that find their CU taken would start only when
-        # another one has walked its whole list.  So from the first bucket's launch until finish() the
-        # engine passes VITMI_LAUNCH_SHARED_DEVICE with every GEMM / attention-backward call (one tile per
-        # workgroup: the dispatcher balances over the free CUs); the forward pass, the start of the
-        # backward and the optimizer — ordered before / after the exchange on the compute stream — keep
-        # the persistent form.  The flag travels with each call (`launch_flags`, ABI 105): nothing
-        # process-wide is switched, so an exception in backward cannot leave another engine degraded.
+        if transport == "auto":
+            transport = os.environ.get("VITMI_COMM", "auto")
+        if transport == "auto":
+            on_gpu = pack.flat.is_cuda
+            nccl = dist.is_initialized() and dist.get_backend(group) == "nccl"
+            transport = "rccl" if on_gpu and (nccl or not dist.is_initialized()) else "pg"
+        if transport not in ("rccl", "pg"):
+            raise ValueError(f"GradReducer: unknown transport {transport!r}")
+        self.transport = transport
+        self.comm = None
+        if transport == "rccl" and (self.world > 1 or self.force):
+            from .comm import default_comm
+            self.comm = default_comm(group)          # collective over the group's ranks the first time
+        # RCCL's all-reduce kernels hold a few dozen CUs while a bucket is in flight, and a 256x256-tile GEMM /
+        # attention-backward workgroup needs a whole CU: with the persistent grids (a FIXED list of tiles / pairs per
+        # workgroup) the workgroups that find their CU taken would start only when another one has walked its whole list.
+        # So the launches that RUN BESIDE a bucket carry VITMI_LAUNCH_SHARED_DEVICE (one tile per workgroup: the
+        # dispatcher balances over the free CUs).  Which launches are those?  The all-reduce starts when the compute
+        # stream reaches the bucket's fork event, i.e. it overlaps the kernels enqueued right AFTER the flush; a 28-MB
+        # bucket (one ViT-B block) is 0.2-0.5 ms on xGMI (2 * 7/8 * 28 MB at 150-300 GB/s of bus bandwidth), the next
+        # three launches of the backward (fc2 data gradient, two weight gradients) are 0.6 ms.  Round 4 flagged EVERY
+        # launch from the first bucket to finish() (+3.0-3.8 % on one GPU, VERDICT r04 item 14); now only the
+        # `shared_launches` launches after each flush are (VITMI_DDP_SHARED_LAUNCHES, default 3; the host cannot ask
+        # whether a bucket is "still outstanding": it runs many kernels ahead of the GPU, and inside a graph capture
+        # there is nothing to query).  The flag travels with each call (`launch_flags`, ABI 105): nothing process-wide
+        # is switched, so an exception in backward cannot leave another engine degraded.
+        self.shared_launches = max(0, int(os.environ.get("VITMI_DDP_SHARED_LAUNCHES", "3")))
+        self._shared_left = 0
         self.comm_active = False
         self.min_bucket = int(min_bucket_elems)
         self._pending_lo: Optional[int] = None
@@ -77,16 +106,23 @@ class GradReducer:
             self._ev_last = torch.cuda.Event(enable_timing=True)
             self._ev_last.record()
         self.comm_active = True
-        self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._shared_left = self.shared_launches
+        if self.comm is not None:
+            self.comm.allreduce_async(buf)        # comm stream ordered after the kernels queued so far; returns at once
+        else:
+            self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self.launched.append((lo, hi))
 
     def finish(self) -> None:
         """Order the current stream after every outstanding bucket."""
         self._flush()
+        if self.comm is not None:
+            self.comm.join()              # the compute stream waits for the comm stream's last bucket
         for w in self._works:
             w.wait()                      # the compute stream waits; kernels launched from here on run after the exchange
         self._works.clear()
         self.comm_active = False
+        self._shared_left = 0
         if self.timing and self._ev_last is not None:
             self._ev_done = torch.cuda.Event(enable_timing=True)
             self._ev_done.record()
@@ -101,12 +137,17 @@ class GradReducer:
     def launch_flags(self) -> int:
         """What the engine passes as `launch_flags` right now (vitmi.h VITMI_LAUNCH_*)."""
         from ._lib import LAUNCH_SHARED_DEVICE
-        return LAUNCH_SHARED_DEVICE if self.comm_active else 0
+        if self.comm_active and self._shared_left > 0:
+            self._shared_left -= 1
+            return LAUNCH_SHARED_DEVICE
+        return 0
 
     def abort(self) -> None:
         """After an exception inside backward: join what was launched, drop what was pending."""
         self._pending_lo = self._pending_hi = None
         try:
+            if self.comm is not None:
+                self.comm.join()
             for w in self._works:
                 w.wait()
         finally:
@@ -114,6 +155,35 @@ class GradReducer:
             self.comm_active = False
 
     def broadcast_parameters(self, src: int = 0) -> None:
-        if self.world > 1:
-            dist.broadcast(self.pack.flat, src=src, group=self.group)
+        """`src`: rank within the group."""
+        if self.world > 1 or (self.force and self.comm is not None):
+            if self.comm is not None:
+                self.comm.broadcast(self.pack.flat, root=src)
+            else:
+                gsrc = dist.get_global_rank(self.group, src) if self.group is not None else src
+                dist.broadcast(self.pack.flat, src=gsrc, group=self.group)
             self.pack.invalidate_shadow()     # the master was written behind the version counters (ADVICE r2)
+
+    def capturable(self) -> bool:
+        """Can a HIP-graph capture of the step contain this exchange?  RCCL yes (own communicator or ProcessGroupNCCL),
+        gloo no."""
+        if self.comm is not None or not (self.world > 1 or self.force):
+            return True
+        return dist.is_initialized() and dist.get_backend(self.group) == "nccl"
+
+    def allreduce_metrics(self, vec: torch.Tensor) -> torch.Tensor:
+        """In-place SUM of a small fp32 vector over the ranks (the epoch's loss sum / correct count), on the transport the
+        buckets use."""
+        if self.comm is not None and vec.is_cuda:
+            self.comm.allreduce(vec)
+        elif self.world > 1:
+            dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=self.group)
+        return vec
+
+    def transport_info(self) -> dict:
+        """For the bench line: what moved the buckets, and what RCCL itself says about the communicator."""
+        out = {"transport": "libvitmi_comm (own ncclComm_t)" if self.comm is not None else
+               f"torch.distributed ProcessGroup ({dist.get_backend(self.group) if dist.is_initialized() else 'none'})"}
+        if self.comm is not None:
+            out.update(self.comm.info())
+        return out

@@ -18,14 +18,26 @@ Limits (checked or documented): parameters must only be changed by the captured 
 between replays (re-capture after load_state_dict or a learning-rate change: the LR is a
 kernel argument baked into the graph; `step.recapture()`).
 
-Data parallelism: an engine with a `ddp.GradReducer` is captured WITH its gradient exchange —
-ProcessGroupNCCL's collectives are capturable (the bucket all-reduces become nodes on RCCL's
-stream inside the graph, joined to the compute stream by the events `Work.wait()` records), so
-launch-bound configurations (dino_vits16 at 32x32: 9.5 ms eager, 3.7 ms replayed) keep the graph
-at N > 1.  The warm-up steps run the exchange eagerly first (the communicator must exist before
-a capture starts); every rank must capture and replay the same number of times.
+Data parallelism: an engine with a `ddp.GradReducer` is captured WITH its gradient exchange — the
+bucket all-reduces become nodes on the comm stream inside the graph (libvitmi_comm's fork event /
+ncclAllReduce / join event; ProcessGroupNCCL's collectives with `VITMI_COMM=pg`), so launch-bound
+configurations (dino_vits16 at 32x32: 9.5 ms eager, 3.7 ms replayed) keep the graph at N > 1.  The
+warm-up steps run the exchange eagerly first (the communicator must exist before a capture starts);
+every rank must capture and replay the same number of times.
+
+Two crashes of round 4 and the contract that came out of them:
+* Captures run in `capture_error_mode="thread_local"`: only the CAPTURING thread's unsafe calls invalidate the
+  capture, so a helper thread of the process (ProcessGroupNCCL's watchdog polling `hipEventQuery`, a DataLoader's
+  pin-memory thread) is legal beside it.  With the own RCCL communicator no helper thread holds an event of the
+  exchange at all; the `time.sleep(0.35)` that used to "let the watchdog retire" the warm-up is gone.
+* ONE live GraphedStep per engine, and nothing is initialised inside a capture: the engine is resolved EAGERLY and
+  pinned before the capture starts (a model whose configuration changed since the last capture gets a new engine —
+  new flat buffers, lazily built tables — and therefore an eager warm-up step first), and a second GraphedStep on an
+  engine that still has a live one is refused (`close()` the first, or `recapture()` it).
 """
 from __future__ import annotations
+
+import weakref
 
 import torch
 
@@ -38,12 +50,16 @@ class GraphedStep:
             raise VitmiError("GraphedStep needs example inputs on the GPU")
         eng = model.engine() if hasattr(model, "engine") else None
         red = getattr(eng, "reducer", None) if eng is not None else None
-        if red is not None and (red.world > 1 or red.force):
-            import torch.distributed as dist
-            backend = dist.get_backend(red.group) if dist.is_initialized() else None
-            if backend != "nccl":
-                raise VitmiError(f"GraphedStep can capture the gradient exchange on RCCL ('nccl') only: a {backend!r} "
-                                 "all_reduce of device tensors is not capturable — run the step eagerly")
+        if red is not None and (red.world > 1 or red.force) and not red.capturable():
+            raise VitmiError("GraphedStep can capture the gradient exchange on RCCL only (libvitmi_comm, or backend 'nccl'): "
+                             "a gloo all_reduce of device tensors is not capturable — run the step eagerly")
+        if eng is not None:
+            other = getattr(eng, "_graphed_step", None)
+            other = other() if other is not None else None
+            if other is not None and other.graph is not None:
+                raise VitmiError("this model's engine already has a live GraphedStep: two captured steps over one engine "
+                                 "share its flat buffers, optimizer state and cached tables — call close() on the first "
+                                 "(or recapture() it) instead of building a second")
         if red is not None and warmup < 1:
             raise VitmiError("GraphedStep with a GradReducer needs warmup >= 1: the RCCL communicator must be "
                              "created by an eager exchange before the capture starts")
@@ -58,7 +74,17 @@ class GraphedStep:
         self.warm_loss = None
         self._lrs = None
         self._pack = None
+        self._engine = None               # the engine the live graph was captured on
         self.recapture(self.warmup)
+
+    def close(self):
+        """Drop the graph (its private memory pool goes back to the allocator); the engine may be captured again."""
+        self.graph = None
+        self.out = self.loss = None
+        eng = self._engine
+        if eng is not None and getattr(eng, "_graphed_step", None) is not None and eng._graphed_step() is self:
+            eng._graphed_step = None
+        self._engine = None
 
     def _eager(self):
         self.optimizer.zero_grad(set_to_none=True)
@@ -72,6 +98,14 @@ class GraphedStep:
         """(Re)build the graph from the current parameters and optimizer settings; `warmup`
         eager steps first (0 for a re-capture: everything is initialised already)."""
         self.graph = None
+        # Resolve the engine EAGERLY and pin it.  `model.engine()` rebuilds the engine when the model's configuration moved
+        # (a DropPath rate edited, a head installed, parameters replaced): new flat buffers, new lazily built tables.  If that
+        # happened since the last capture, or this is the first capture, the new engine's first step must run EAGERLY — lazy
+        # initialisation (LDS attributes, workspaces, host-built index tables = synchronous copies) is illegal inside a
+        # capture, raises there, and the capture_end that follows an invalidated capture is where round 4's segfault sat.
+        eng = self.model.engine() if hasattr(self.model, "engine") else None
+        if eng is not None and eng is not self._engine and warmup < 1:
+            warmup = 1
         # the warm-up passes run on a side stream (torch's capture recipe), so AccumulateGrad
         # nodes of earlier eager steps live on another stream: expected here, not a hazard
         quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
@@ -85,14 +119,11 @@ class GraphedStep:
                 self.warm_out, self.warm_loss = out.detach().clone(), loss.detach().clone()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        eng_ = self.model.engine() if hasattr(self.model, "engine") else None
-        if getattr(eng_, "reducer", None) is not None:
-            # ProcessGroupNCCL's watchdog thread polls the events of the eager warm-up's collectives every 100 ms and ABORTS the
-            # process when a query fails ("operation not permitted on an event last recorded in a capturing stream": seen once in
-            # round 4, beside a capture).  Everything eager has completed (synchronize above): let the watchdog retire it before
-            # the capture starts, so that it holds nothing while the stream captures.
-            import time
-            time.sleep(0.35)
+        if eng is not None:
+            if self.model.engine() is not eng:
+                raise VitmiError("the model's engine changed during the warm-up steps: cannot capture")
+            self._engine = eng
+            eng._graphed_step = weakref.ref(self)
         # The engine's fp32 -> bf16 weight cast stays OUT of the graph when the captured optimizer is one of the fused ones
         # over ALL of the pack's trainable parameters: those kernels write master and shadow in one pass, so inside the
         # replay loop the shadow is always current, and __call__ checks the pack's version key eagerly before every replay
@@ -104,7 +135,8 @@ class GraphedStep:
         g = torch.cuda.CUDAGraph()
         self.optimizer.zero_grad(set_to_none=True)
         try:
-            with torch.cuda.graph(g):
+            # thread_local: only this thread's unsafe calls invalidate the capture (module docstring)
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 out = self.model(self.x)
                 loss = self.criterion(out, self.y)
                 loss.backward()

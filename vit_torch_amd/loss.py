@@ -29,7 +29,15 @@ class _XentFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dlogits,) = ctx.saved_tensors
-        return dlogits * g, None, None
+        # d loss -> d logits: the upstream gradient is a device scalar (1.0 for `loss.backward()`); the product runs on
+        # vitmi_scale_cast (the [B, K] gradient as one row, the scalar as that row's factor) so that no ATen math is left
+        # inside the step; a B*K that is not a multiple of 4 keeps the ATen product
+        n = dlogits.numel()
+        if n % 4 or not dlogits.is_cuda:
+            return dlogits * g, None, None
+        out = torch.empty_like(dlogits)
+        ops.scale_cast(dlogits, out, None, M=1, N=n, rowscale=g.detach().reshape(1).float(), rows_per_group=1)
+        return out, None, None
 
 
 class CrossEntropyLoss(nn.Module):

@@ -183,6 +183,18 @@ def _timing_events(eng):
     return (torch.cuda.Event(enable_timing=True, external=ext), torch.cuda.Event(enable_timing=True, external=ext))
 
 
+def _rows_padded(*tensors) -> bool:
+    """True when every given [M, .] tensor's storage reaches ceil256(M) rows at its row stride."""
+    for t in tensors:
+        if t is None or t.dim() != 2:
+            continue
+        rows = (t.shape[0] + 255) // 256 * 256
+        need = (t.storage_offset() + (rows - 1) * t.stride(0) + t.shape[1]) * t.element_size()
+        if t.untyped_storage().nbytes() < need:
+            return False
+    return True
+
+
 def engine_gemm(eng, A, B, C, **k):
     """ops.gemm with the engine's implementation switch; when eng.profile is a list, each
     launch is bracketed by HIP events on the launch stream (bench.py's roofline leg)."""
@@ -193,7 +205,10 @@ def engine_gemm(eng, A, B, C, **k):
         k.setdefault("aux_deriv", eng.T == torch.bfloat16)
     if eng.reducer is not None:             # gradient buckets in flight: share the device with RCCL's kernels
         k.setdefault("launch_flags", eng.reducer.launch_flags())
-    if getattr(eng, "pad_rows", False):     # every [M, .] activation of this engine is allocated to a multiple of 256 rows
+    if getattr(eng, "pad_rows", False) and _rows_padded(C, k.get("C2"), k.get("R"), k.get("aux")):
+        # every [M, .] activation of this engine comes from _alloc (rows rounded up to 256); the flag is only passed when the
+        # storage behind each row-indexed output / side input really covers the padding (a future torch.empty
+        # output would otherwise be a silent out-of-bounds write of up to 255 rows)
         k["launch_flags"] = k.get("launch_flags", 0) | LAUNCH_ROWS_PADDED
     if eng.profile is None:
         return ops.gemm(A, B, C, impl=eng.gemm_impl, **k)
@@ -287,6 +302,10 @@ class VitEngine:
         # repeated, surplus output rows into the padding) instead of the slower 256x128 ragged form.  VITMI_PAD_ROWS=0: off.
         self.pad_rows = self.T == torch.bfloat16 and os.environ.get("VITMI_PAD_ROWS", "1") != "0"
         self.cls_last = bool(getattr(model, "cls_only_last_block", False))
+        if self.cls_last and model.embed_dim // model.blocks[0].attn.num_heads > 64:
+            # the one-query form runs on the class-attention kernels (cait_ops.hip): hd <= 64 (and N <= 256, checked per input)
+            raise VitmiError("cls_only_last_block needs head_dim <= 64 (the class-attention kernels' limit); got "
+                             f"{model.embed_dim // model.blocks[0].attn.num_heads}: build the model without the option")
 
     def _alloc(self, rows, cols, dt, dev, zero=False):
         r = (rows + 255) // 256 * 256 if self.pad_rows else rows
@@ -349,6 +368,9 @@ class VitEngine:
         H = m.blocks[0].attn.num_heads
         hd = D // H
         Kp = Cin * p * p
+        if self.cls_last and N > 256:
+            raise VitmiError(f"cls_only_last_block needs at most 256 tokens per image (the class-attention kernels' limit); this "
+                             f"input has {N}: build the model without the option")
         self.pack.refresh_shadow()
 
         def new(rows, cols, dt):
