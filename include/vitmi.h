@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VITMI_VERSION 108
+#define VITMI_VERSION 109
 
 enum { VITMI_F32 = 0, VITMI_BF16 = 1 };
 
@@ -319,6 +319,23 @@ int vitmi_token_mean(const void* x, float* out, const float* dout, void* dx, int
                      int64_t B, int64_t L, int64_t C, void* stream);
 
 /* ---------------------------------------------------------- Elementwise --*/
+/* "bf16x3" parity mode (ABI 109): fp32 arithmetic of the reference (/root/reference/main.py:244,
+ * utils_network.py:120 — nn.Linear / Conv2d on fp32 tensors) on the bf16 matrix pipe.  x = hi + lo with
+ * hi = bf16(x), lo = bf16(x - hi); an fp32 [rows, cols] matrix is written as the bf16 image
+ *   A pattern (b_pattern = 0): hi | lo | hi        B pattern (b_pattern = 1): hi | hi | lo
+ * so that ONE vitmi_gemm over K' = 3K of an A-pattern and a B-pattern operand accumulates
+ * a_hi b_hi + a_lo b_hi + a_hi b_lo in fp32 (error O(2^-16) per product instead of bf16's 2^-9).
+ * stacked = 0: the three parts side by side along the row (out is [rows, 3 cols], ldo >= 3 cols): a k-major operand;
+ * stacked = 1: three row blocks (out is [3 rows, cols], ldo >= cols): a k-minor operand (k = the row index).
+ * cols, ldx, ldo multiples of 4; x 16-byte, out 8-byte aligned. */
+int vitmi_split3(const float* x, int64_t ldx, int64_t rows, int64_t cols, void* out_bf16, int64_t ldo,
+                 int b_pattern, int stacked, void* stream);
+/* fp32 halves of the two GELU epilogues for that mode (the tile kernel builds them for bf16 outputs only):
+ * out = gelu(pre) (erf form, nn.GELU() default: models/swin.py:14-30);  out = dh * gelu'(pre). */
+int vitmi_gelu_fwd(const float* pre, int64_t ldp, float* out, int64_t ldo, int64_t M, int64_t N, void* stream);
+int vitmi_gelu_bwd(const float* dh, int64_t ldd, const float* pre, int64_t ldp, float* out, int64_t ldo,
+                   int64_t M, int64_t N, void* stream);
+
 /* fp32 -> bf16 shadow copy of the flat parameter buffer */
 int vitmi_cast(const void* src, int src_dtype, void* dst, int dst_dtype,
                int64_t n, void* stream);

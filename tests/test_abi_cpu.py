@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_version_and_error_string(lib):
-    assert lib.vitmi_version() == 108
+    assert lib.vitmi_version() == 109
     assert isinstance(lib.vitmi_last_error_string(), bytes)
 
 

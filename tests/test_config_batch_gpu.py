@@ -38,13 +38,13 @@ RECORDS = ["oracle_dino_vitb16_bs256", "oracle_dino_vitb8_96_bs128", "oracle_din
 def _check(name, compute, residual, graph):
     import bench
     r = bench.fixture_parity(name, compute, residual, graph)
-    tol = bench.PARITY_TOL["fp32" if compute == "fp32" else "bf16"]
+    tol = bench.PARITY_TOL["bf16" if compute == "bf16" else "fp32"]
     print(f"\n{name} [{compute} operands, {residual} stream, {'graph replay' if graph else 'eager'}]: {r}")
     assert r["logits_rel"] <= tol["logits_rel"], r
     assert r["loss_diff"] <= tol["loss_diff"], r
     assert r["gradnorm_rel"] <= tol["gradnorm_rel"], r
     assert r["gradsample_cos_min"] >= tol["grad_cos_min"], r
-    if compute == "fp32":
+    if compute != "bf16":
         assert r["gradsample_rel"] <= 1e-3, r
     return r
 
@@ -76,3 +76,14 @@ def test_graph_replay_at_the_configuration_batch(name):
     """The step as bench.py times it: GraphedStep(model, CrossEntropyLoss, FusedSGD(lr 1e-3, momentum 0.9)), one replay
     from the record's weights."""
     _check(name, "bf16", "bf16", True)
+
+
+@pytest.mark.parametrize("name", [n for n in RECORDS if not n.startswith("full_cait")])
+def test_bf16x3_mode_meets_the_fp32_tolerance_at_the_configuration_batch(name):
+    """Round 5: compute_dtype="bf16x3" — fp32 activations and weights, every GEMM as one bf16 product
+    over 3K of the operands' hi / lo halves (a b = a_hi b_hi + a_lo b_hi + a_hi b_lo) on the tile kernel — held to the
+    FP32 mode's bounds: logits, loss, gradient norms and sampled gradient entries within 1e-3 (measured ~1e-5), at the
+    batch the benchmark runs at.  CaiT's LayerScale epilogue (second output) is not built for this mode."""
+    r = _check(name, "bf16x3", "fp32", False)
+    if name == "oracle_dino_vitb16_bs256":
+        assert r["gemm_flop_share_on_256x256_tiles"] > 0.999, r

@@ -11,7 +11,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from util import assert_close, bf16_round
+from util import assert_close, bf16_round, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -1189,3 +1189,67 @@ def test_gemm_ragged_m_fp32_output_never_splits_k(ops):
     torch.cuda.synchronize()
     assert_close("ragged nn fp32", C, a @ b.t(), 1e-4)
     assert torch.isnan(cbuf[Mp:]).all(), "rows beyond the padding were written"
+
+
+# ------------------------------------------------------------- "bf16x3": fp32 products as three bf16 products ---
+@pytest.mark.parametrize("stacked", [False, True])
+@pytest.mark.parametrize("b_pattern", [False, True])
+def test_split3_images(ops, stacked, b_pattern):
+    """vitmi_split3: hi = bf16(x), lo = bf16(x - hi); A pattern hi|lo|hi, B pattern hi|hi|lo, side by side (k-major) or
+    stacked (k-minor).  Bit-exact against the same two roundings in torch; hi + lo recovers x to 2^-16."""
+    R, Cn = 37, 64
+    x = gen((R, Cn), 21) * 3.0
+    out = ops.split3(dev(x), b_pattern=b_pattern, stacked=stacked).float().cpu()
+    hi = x.to(torch.bfloat16).float()
+    lo = (x - hi).to(torch.bfloat16).float()
+    parts = [hi, hi, lo] if b_pattern else [hi, lo, hi]
+    want = torch.cat(parts, dim=0 if stacked else 1)
+    assert torch.equal(out, want)
+    assert ((hi + lo) - x).abs().max().item() <= 2.0 ** -16 * x.abs().max().item()
+
+
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("M,N,K", [(512, 256, 128), (300, 96, 160), (1024, 768, 768)])
+def test_gemm_split3_is_fp32_grade(ops, layout, M, N, K):
+    """Three bf16 products of the hi / lo halves against the fp64 product of the fp32 operands: 1e-5 of the result's
+    scale (a plain bf16 product of the same operands is ~4e-3)."""
+    akm, bkm = {"nt": (True, True), "nn": (True, False), "tn": (False, False)}[layout]
+    if layout == "tn":
+        M, K = M // 8 * 8, K // 32 * 32
+    a, b = gen((M, K), 31), gen((N, K), 32) * 0.3
+    want = (a.double() @ b.double().t()).float()
+    A = dev(a if akm else a.t().contiguous())
+    B = dev(b if bkm else b.t().contiguous())
+    C = torch.empty((M, N), device="cuda")
+    ops.gemm_split3(A, B, C, a_kmajor=akm, b_kmajor=bkm)
+    assert_close(f"split3[{layout}]", C, want, 2e-5)
+    Cb = torch.empty((M, N), device="cuda")
+    ops.gemm(A.to(torch.bfloat16), B.to(torch.bfloat16), Cb, a_kmajor=akm, b_kmajor=bkm)
+    assert rel_err(Cb, want) > 20 * rel_err(C, want)
+
+
+def test_gemm_split3_epilogues(ops):
+    from vit_torch_amd._lib import EPI_BIAS_GELU, EPI_DGELU, EPI_PATCH_POS, EPI_RESIDUAL
+    M, N, K = 788, 256, 192          # 4 images x 197 tokens
+    a, w, bias = gen((M, K), 41), gen((N, K), 42) * 0.2, gen((N,), 43)
+    acc = (a.double() @ w.double().t()).float()
+    A, W, Wt, bd = dev(a), dev(w), dev(w.t().contiguous()), dev(bias)
+    H, P = torch.empty((M, N), device="cuda"), torch.empty((M, N), device="cuda")
+    ops.gemm_split3(A, W, H, epilogue=EPI_BIAS_GELU, bias=bd, C2=P)
+    assert_close("pre", P, acc + bias, 2e-5)
+    assert_close("gelu", H, F.gelu(acc + bias), 2e-5)
+    r = gen((M, N), 44)
+    X = torch.empty((M, N), device="cuda")
+    ops.gemm_split3(A, W, X, epilogue=EPI_RESIDUAL, bias=bd, R=dev(r))
+    assert_close("residual", X, r + acc + bias, 2e-5)
+    d, pre = gen((M, N), 45), gen((M, N), 46)
+    dx = torch.empty((M, K), device="cuda")
+    ops.gemm_split3(dev(d), W, dx, b_kmajor=False, epilogue=EPI_DGELU, aux=dev(gen((M, K), 47)))
+    want = (d.double() @ w.double()).float() * gelu_grad(gen((M, K), 47))
+    assert_close("dgelu", dx, want, 3e-5)
+    pos, cls = gen((197, N), 48), gen((N,), 49)
+    Xp = torch.empty((M, N), device="cuda")
+    ops.gemm_split3(A, W, Xp, epilogue=EPI_PATCH_POS, bias=bd, pos=dev(pos), n_tok=197, cls=dev(cls))
+    wantp = (acc + bias).view(4, 197, N) + pos
+    wantp[:, 0] = cls + pos[0]
+    assert_close("patch_pos", Xp, wantp.reshape(M, N), 2e-5)

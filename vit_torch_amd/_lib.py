@@ -113,6 +113,9 @@ SIGNATURES = {
     "vitmi_relpos_bias": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]),
     "vitmi_patch_merge": (C.c_int, [c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_i64, C.c_int, c_vp]),
     "vitmi_token_mean": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, c_i64, c_i64, c_i64, c_vp]),
+    "vitmi_split3": (C.c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, C.c_int, C.c_int, c_vp]),
+    "vitmi_gelu_fwd": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp]),
+    "vitmi_gelu_bwd": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp]),
     "vitmi_cast": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int, c_i64, c_vp]),
     "vitmi_axpy": (C.c_int, [c_vp, c_vp, c_f32, c_i64, c_vp]),
     "vitmi_scale_cast": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, c_vp, c_i64, c_vp, C.c_int, c_i64, c_i64, c_i64, c_vp]),

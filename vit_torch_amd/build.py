@@ -30,6 +30,7 @@ SOURCES = [
     "gemm_small.hip",
     "layernorm.hip",
     "elementwise.hip",
+    "split3.hip",
     "ingest.hip",
     "posembed.hip",
     "optim.hip",

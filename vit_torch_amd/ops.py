@@ -67,6 +67,54 @@ def gemm(A, B, C_out, *, a_kmajor=True, b_kmajor=True, epilogue=EPI_STORE, bias=
     return C_out
 
 
+def split3(x, *, b_pattern: bool, stacked: bool):
+    """The bf16 image of an fp32 matrix for the "bf16x3" mode (vitmi_split3): [rows, 3 cols] (k-major operand) or
+    [3 rows, cols] (k-minor operand), A pattern hi|lo|hi or B pattern hi|hi|lo."""
+    _need_cuda(x)
+    assert x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1
+    R, Cn = x.shape
+    out = torch.empty((3 * R, Cn) if stacked else (R, 3 * Cn), dtype=torch.bfloat16, device=x.device)
+    check(load().vitmi_split3(x.data_ptr(), x.stride(0), R, Cn, out.data_ptr(), out.stride(0), int(b_pattern), int(stacked),
+                              _stream()), "vitmi_split3")
+    return out
+
+
+def gelu_fwd(pre, out):
+    _need_cuda(pre, out)
+    M, N = pre.shape
+    check(load().vitmi_gelu_fwd(pre.data_ptr(), pre.stride(0), out.data_ptr(), out.stride(0), M, N, _stream()), "vitmi_gelu_fwd")
+    return out
+
+
+def gelu_bwd(dh, pre, out):
+    _need_cuda(dh, pre, out)
+    M, N = pre.shape
+    check(load().vitmi_gelu_bwd(dh.data_ptr(), dh.stride(0), pre.data_ptr(), pre.stride(0), out.data_ptr(), out.stride(0),
+                                M, N, _stream()), "vitmi_gelu_bwd")
+    return out
+
+
+def gemm_split3(A, B, C_out, *, a_kmajor=True, b_kmajor=True, epilogue=EPI_STORE, bias=None, aux=None, C2=None,
+                aux_deriv=False, colsum_part=None, **k):
+    """`gemm` for fp32 operands in the "bf16x3" mode: both operands are written as their three-part bf16 images
+    (`split3`) and ONE bf16 product over K' = 3K runs on the tile kernels with the fp32 epilogue asked for.  The two GELU
+    epilogues (bf16-only on the tile kernel) become a plain fp32 product + the element-wise fp32 kernel."""
+    assert A.dtype == torch.float32 and B.dtype == torch.float32 and C_out.dtype == torch.float32
+    assert colsum_part is None and not aux_deriv
+    if not A.is_contiguous() and A.stride(1) != 1:
+        A = A.contiguous()
+    A3 = split3(A, b_pattern=False, stacked=not a_kmajor)
+    B3 = split3(B, b_pattern=True, stacked=not b_kmajor)
+    if epilogue == EPI_BIAS_GELU:
+        pre = C2 if C2 is not None else torch.empty_like(C_out)
+        gemm(A3, B3, pre, a_kmajor=a_kmajor, b_kmajor=b_kmajor, bias=bias, **k)
+        return gelu_fwd(pre, C_out)
+    if epilogue == EPI_DGELU:
+        gemm(A3, B3, C_out, a_kmajor=a_kmajor, b_kmajor=b_kmajor, **k)
+        return gelu_bwd(C_out, aux, C_out)
+    return gemm(A3, B3, C_out, a_kmajor=a_kmajor, b_kmajor=b_kmajor, epilogue=epilogue, bias=bias, C2=C2, **k)
+
+
 def gemm_pair(A0, B0, C0, A1, B1, C1, launch_flags=0):
     """Two weight-gradient products C_i = A_i^T @ B_i (k-minor operands [tokens, features], fp32 C) in one launch where
     the library can pair them (vitmi_gemm_pair), else one after the other; same results."""

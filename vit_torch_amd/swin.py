@@ -142,6 +142,7 @@ class SwinTransformer(nn.Module):
         self.mlp_ratio = mlp_ratio
         self.apply_head = True
         self.compute_dtype = _DT[compute_dtype]
+        self.split3 = compute_dtype == "bf16x3"        # vit.py: fp32 GEMMs as three bf16 products (ops.gemm_split3)
         # the residual stream between the blocks: "fp32" (default: the reference trains in fp32, and the fp32 stream ends a
         # 50-step run within 0.06-0.08 % of the oracle loss, tests/test_training_curve_gpu.py), "bf16" (what bench.py times:
         # 1.1-2.2 % on the same test), or "auto" = follow the compute dtype
@@ -216,6 +217,7 @@ class SwinEngine:
         if dev.type != "cuda":
             raise VitmiError("move the model to the GPU before the first forward")
         self.T, self.R = model.compute_dtype, model.residual_dtype
+        self.split3 = bool(getattr(model, "split3", False))
         if self.T == torch.float32 and self.R != torch.float32:
             raise VitmiError("fp32 compute needs an fp32 residual stream")
         self.head = _head_layers(model.head)
@@ -254,6 +256,7 @@ class SwinEngine:
     def is_current(self):
         m = self.model
         return (self.pack.is_current() and m.compute_dtype == self.T and m.residual_dtype == self.R
+                and bool(getattr(m, "split3", False)) == self.split3
                 and len(self.pack.params) == sum(1 for _ in m.parameters()) and self._dp_current())
 
     def _w(self, p):

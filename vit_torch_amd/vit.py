@@ -29,7 +29,10 @@ from .packing import ParamPack
 from .posembed import tables_for
 from .data import PatchRows
 
-_DT = {"bf16": torch.bfloat16, "fp32": torch.float32, torch.bfloat16: torch.bfloat16,
+# compute_dtype: "bf16" (bf16 operands, fp32 accumulate: the benchmarked mode), "fp32" (fp32 MFMA / VALU: the exact parity
+# mode) or "bf16x3" (round 5: fp32 activations and weights, every GEMM as three bf16 products of hi / lo operand halves on
+# the tile kernel — ops.gemm_split3, csrc/split3.hip: fp32-grade products at a third of the bf16 rate instead of 1/80)
+_DT = {"bf16": torch.bfloat16, "fp32": torch.float32, "bf16x3": torch.float32, torch.bfloat16: torch.bfloat16,
        torch.float32: torch.float32}
 
 
@@ -91,6 +94,7 @@ class VisionTransformer(nn.Module):
         # computes the other 196 rows and discards them), ~6 % fewer FLOPs per step.  tests/test_vit_gpu.py compares.
         self.cls_only_last_block = bool(cls_only_last_block)
         self.compute_dtype = _DT[compute_dtype]
+        self.split3 = compute_dtype == "bf16x3"
         # the residual stream between the blocks: "fp32" (default: the reference trains in fp32, and the fp32 stream ends a
         # 50-step run within 0.06-0.08 % of the oracle loss, tests/test_training_curve_gpu.py), "bf16" (what bench.py times:
         # 1.1-2.2 % on the same test), or "auto" = follow the compute dtype
@@ -195,12 +199,36 @@ def _rows_padded(*tensors) -> bool:
     return True
 
 
+def _engine_gemm_split3(eng, A, B, C, **k):
+    """engine_gemm in the "bf16x3" mode: fp32 operands -> three-part bf16 images -> ONE bf16 product over 3K on the tile
+    kernels, fp32 epilogue (ops.gemm_split3).  Profiled launches count the algorithmic 2 M N K FLOPs (the mode's own
+    roofline is a third of the bf16 peak)."""
+    if eng.reducer is not None:
+        k.setdefault("launch_flags", eng.reducer.launch_flags())
+    if k.get("C2") is not None and k.get("epilogue") == EPI_RESIDUAL:
+        raise VitmiError("compute_dtype='bf16x3': the residual epilogue's second output (LayerScale branch, CaiT) is not "
+                         "available in this mode; use compute_dtype='fp32'")
+    if eng.profile is None:
+        return ops.gemm_split3(A, B, C, **k)
+    akm, bkm = k.get("a_kmajor", True), k.get("b_kmajor", True)
+    Kdim = A.shape[1] if akm else A.shape[0]
+    e0, e1 = _timing_events(eng)
+    e0.record()
+    ops.gemm_split3(A, B, C, **k)
+    e1.record()
+    name = "gemm3_" + ("n" if akm else "t") + ("t" if bkm else "n")
+    eng.profile.append((name, (C.shape[0], C.shape[1], Kdim), 2.0 * C.shape[0] * C.shape[1] * Kdim, e0, e1))
+    return C
+
+
 def engine_gemm(eng, A, B, C, **k):
     """ops.gemm with the engine's implementation switch; when eng.profile is a list, each
     launch is bracketed by HIP events on the launch stream (bench.py's roofline leg)."""
     # the block MLPs keep gelu'(pre) instead of pre in bf16 mode: the GELU epilogue has the exp
     # at hand, and the backward epilogue becomes a multiply (vitmi_gemm_desc.aux_is_derivative).
     # fp32 (parity) mode keeps the pre-activation, as the reference's autograd does.
+    if getattr(eng, "split3", False) and A.dtype == torch.float32:
+        return _engine_gemm_split3(eng, A, B, C, **k)
     if k.get("epilogue") in (EPI_BIAS_GELU, EPI_DGELU):
         k.setdefault("aux_deriv", eng.T == torch.bfloat16)
     if eng.reducer is not None:             # gradient buckets in flight: share the device with RCCL's kernels
@@ -277,6 +305,7 @@ class VitEngine:
             raise VitmiError("move the model to the GPU before the first forward")
         self.T = model.compute_dtype
         self.R = model.residual_dtype
+        self.split3 = bool(getattr(model, "split3", False))
         if self.T == torch.float32 and self.R != torch.float32:
             raise VitmiError("fp32 compute needs an fp32 residual stream")
         self.head = _head_layers(model.head) if model.apply_head else []
@@ -315,6 +344,7 @@ class VitEngine:
     def is_current(self) -> bool:
         m = self.model
         return (self.pack.is_current() and m.compute_dtype == self.T and m.residual_dtype == self.R
+                and bool(getattr(m, "split3", False)) == self.split3
                 and len(self.pack.params) == sum(1 for _ in m.parameters())
                 and bool(getattr(m, "cls_only_last_block", False)) == self.cls_last)
 
