@@ -1253,3 +1253,41 @@ def test_gemm_split3_epilogues(ops):
     wantp = (acc + bias).view(4, 197, N) + pos
     wantp[:, 0] = cls + pos[0]
     assert_close("patch_pos", Xp, wantp.reshape(M, N), 2e-5)
+
+
+@pytest.mark.parametrize("B,N,H,hd", [(3, 197, 12, 64), (2, 145, 3, 64), (4, 5, 2, 64), (2, 256, 2, 32), (1, 33, 3, 32)])
+def test_attention_fp32_on_the_matrix_pipe_equals_the_vector_form(ops, lib, B, N, H, hd):
+    """Round 5: fp32 attention on v_mfma_f32_32x32x2_f32 (hd in {32, 64}, N <= 256) against (i) an fp64 evaluation of the
+    reference's formula (models/swin.py:124-142 minus bias / mask) and (ii) the VALU kernels it replaces
+    (vitmi_debug_attn_f32_valu): forward, lse and all three gradients; padded keys / queries must not leak (N = 197, 145,
+    5, 33 are not multiples of 32) and nothing outside the [B, N] rows may be written."""
+    import ctypes
+    from vit_torch_amd import _lib as L
+    raw = ctypes.CDLL(str(L.LIB_PATH))
+    scale = hd ** -0.5
+    qkv = gen((B, N, 3 * H * hd), 51)
+    do = gen((B, N, H * hd), 52)
+    q64 = qkv.double().clone().requires_grad_(True)
+    o_ref, lse_ref = attn_ref(q64, B, N, H, hd, scale)
+    o_ref.backward(do.double())
+    QKV, DO = dev(qkv), dev(do)
+    res = {}
+    for form in ("mfma", "valu"):
+        raw.vitmi_debug_attn_f32_valu(1 if form == "valu" else 0)
+        O = torch.full((B, N, H * hd), float("nan"), device="cuda")
+        lse = torch.full((B * H * N,), float("nan"), device="cuda")
+        dqkv = torch.full((B, N, 3 * H * hd), float("nan"), device="cuda")
+        ops.attn_fwd(QKV, O, lse, B, N, H, hd, scale)
+        ops.attn_bwd(QKV, O, DO, lse, dqkv, B, N, H, hd, scale)
+        torch.cuda.synchronize()
+        res[form] = (O.cpu(), lse.cpu(), dqkv.cpu())
+    raw.vitmi_debug_attn_f32_valu(0)
+    O, lse, dqkv = res["mfma"]
+    assert_close("out", O, o_ref.detach().float(), 3e-6)
+    assert_close("lse", lse.view(B, H, N), lse_ref.detach().float(), 2e-6)
+    g = q64.grad.float().view(B, N, 3, H, hd)
+    d = dqkv.view(B, N, 3, H, hd)
+    for i, nm in enumerate("qkv"):
+        assert_close(f"d{nm}", d[:, :, i], g[:, :, i], 1e-5)
+    assert_close("out vs VALU form", O, res["valu"][0], 3e-6)
+    assert_close("dqkv vs VALU form", dqkv, res["valu"][2], 1e-5)

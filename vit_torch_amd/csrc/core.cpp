@@ -55,6 +55,7 @@ int vitmi_cu_count() {
 // one tile / pair per workgroup, 1 = force the persistent grids
 static std::atomic<int> g_persist_override{-1};
 void vitmi_debug_reset_attention();
+void vitmi_debug_reset_attention_f32();
 void vitmi_debug_reset_cait();
 void vitmi_debug_reset_cait_fused();
 void vitmi_debug_reset_gemm();
@@ -69,6 +70,7 @@ void vitmi_debug_reset_swin();
 extern "C" void vitmi_debug_reset(void) {
   g_persist_override.store(-1, std::memory_order_relaxed);
   vitmi_debug_reset_attention();
+  vitmi_debug_reset_attention_f32();
   vitmi_debug_reset_cait();
   vitmi_debug_reset_cait_fused();
   vitmi_debug_reset_gemm();
