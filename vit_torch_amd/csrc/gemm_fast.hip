@@ -1239,10 +1239,12 @@ static int persistent_grid(int nwg, int launch_flags) {
 // XCDs inside a band; the band is the widest divisor-free choice whose B panels take <= 2 MiB.
 static std::atomic<int> g_band_override{-1};     // diagnostic hook: -1 = automatic, 0 = row-major, n = bands of n column tiles
 extern "C" void vitmi_debug_gemm_band(int n) { g_band_override = n; }
+static std::atomic<int> g_band_min_kb{3072};     // diagnostic hook: B matrices up to this size keep the row-major order
+extern "C" void vitmi_debug_gemm_band_kb(int kb) { g_band_min_kb = kb > 0 ? kb : 3072; }
 static int band_for(const GemmArgs& g, int tiles_m, int tiles_n) {
   if (g_band_override >= 0) return g_band_override;
   const int64_t b_bytes = g.N * g.K * 2;
-  if (b_bytes <= (3 << 20) || tiles_n < 2 || tiles_m < 64) return 0;
+  if (b_bytes <= ((int64_t)g_band_min_kb << 10) || tiles_n < 2 || tiles_m < 64) return 0;
   const int64_t panel = (int64_t)BN * g.K * 2;
   int band = (int)((2 << 20) / panel);
   if (band < 1) band = 1;
@@ -1538,5 +1540,6 @@ void vitmi_debug_reset_gemm_fast() {
   g_stagger_phases = 4;
   g_pipe_override = -1;
   g_band_override = -1;
+  g_band_min_kb = 3072;
   g_tile_override = -1;
 }

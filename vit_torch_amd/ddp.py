@@ -51,7 +51,18 @@ class GradReducer:
         self.comm = None
         if transport == "rccl" and (self.world > 1 or self.force):
             from .comm import default_comm
-            self.comm = default_comm(group)          # collective over the group's ranks the first time
+            try:
+                self.comm = default_comm(group)      # collective over the group's ranks the first time
+            except Exception as e:
+                # libvitmi_comm.so missing / RCCL not bindable / ncclCommInitRank refused: the buckets still go through RCCL,
+                # on torch.distributed's communicator (every rank sees the same failure: the library and RCCL are the same
+                # files on all ranks of a node).  VITMI_COMM=rccl makes this fatal instead.
+                if os.environ.get("VITMI_COMM") == "rccl":
+                    raise
+                import warnings
+                warnings.warn(f"GradReducer: own RCCL communicator unavailable ({type(e).__name__}: {e}); "
+                              "using torch.distributed's ProcessGroupNCCL for the gradient buckets")
+                self.transport = "pg"
         # RCCL's all-reduce kernels hold a few dozen CUs while a bucket is in flight, and a 256x256-tile GEMM /
         # attention-backward workgroup needs a whole CU: with the persistent grids (a FIXED list of tiles / pairs per
         # workgroup) the workgroups that find their CU taken would start only when another one has walked its whole list.
