@@ -9,6 +9,7 @@ cp $G/${T}_bench_n1*.json $P/
 cp $G/${T}_vitb.txt $P/${T}_rocprofv3_summary.txt
 cp $G/${T}_vitb_kernel_stats.csv $P/${T}_rocprofv3_kernel_stats_bench_steps5.csv
 cp $G/${T}_vitb.json $P/${T}_bench_under_rocprof.json
+cp $G/${T}_vitb_buckets.json $P/${T}_rocprof_buckets.json
 cp $G/${T}_vitb_serial.txt $P/${T}_rocprofv3_summary_serial.txt
 cp $G/${T}_vitb_serial_kernel_stats.csv $P/${T}_rocprofv3_kernel_stats_bench_steps5_serial.csv
 cp $G/${T}_vitb_pmc_traffic.json $P/${T}_pmc_traffic.json

@@ -10,6 +10,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$tag -- py
 cd $R
 grep '^{"metric"' gpurun_out/$tag.log > gpurun_out/$tag.json || true
 steps=$(python3 -c "import json;d=json.load(open('gpurun_out/$tag.json'));print(d['steps']+d['warmup']+1)")
-python3 tools/prof_summary.py gpurun_out/$tag $steps 30 > gpurun_out/$tag.txt
+python3 tools/prof_summary.py gpurun_out/$tag $steps 30 gpurun_out/${tag}_buckets.json > gpurun_out/$tag.txt
 cp $(find gpurun_out/$tag -name '*kernel_stats.csv' | head -1) gpurun_out/${tag}_kernel_stats.csv
 rm -rf gpurun_out/$tag
