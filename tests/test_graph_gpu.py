@@ -213,3 +213,28 @@ def test_capture_tolerates_hip_calls_from_another_thread():
     assert not errors, errors
     l = float(gs(x, y).item())
     assert l == l and abs(l) < 1e3
+
+
+def test_bf16x3_step_replays_from_a_graph():
+    """The three-product parity mode allocates its operand images per call (torch.empty inside the capture: the graph's
+    private pool): a replayed step must equal the eager one."""
+    from vit_torch_amd import CrossEntropyLoss, FusedSGD, GraphedStep, VisionTransformer
+    def make():
+        torch.manual_seed(9)
+        m = VisionTransformer(img_size=32, patch_size=16, embed_dim=128, depth=2, num_heads=2, num_classes=10,
+                              compute_dtype="bf16x3", residual_dtype="fp32").cuda()
+        m.head = torch.nn.Linear(128, 10, bias=False).cuda()
+        m.engine()
+        return m, CrossEntropyLoss(), FusedSGD(m.parameters(), lr=1e-2, momentum=0.9)
+    g = torch.Generator("cpu").manual_seed(0)
+    data = [(torch.randn(32, 3, 32, 32, generator=g).cuda(), torch.randint(0, 10, (32,), generator=g).cuda()) for _ in range(3)]
+    m, crit, opt = make()
+    eager = []
+    for x, y in [data[0]] + data:
+        opt.zero_grad(); loss = crit(m(x), y); loss.backward(); opt.step()
+        eager.append(loss.item())
+    m2, crit2, opt2 = make()
+    gs = GraphedStep(m2, crit2, opt2, *data[0], warmup=1)
+    graphed = [gs.warm_loss.item()] + [gs(x, y).item() for x, y in data]
+    assert graphed == pytest.approx(eager, rel=1e-5, abs=1e-6), (graphed, eager)
+    torch.testing.assert_close(m2.engine().pack.flat, m.engine().pack.flat, rtol=1e-5, atol=1e-6)

@@ -206,8 +206,17 @@ def _engine_gemm_split3(eng, A, B, C, **k):
     if eng.reducer is not None:
         k.setdefault("launch_flags", eng.reducer.launch_flags())
     if k.get("C2") is not None and k.get("epilogue") == EPI_RESIDUAL:
-        raise VitmiError("compute_dtype='bf16x3': the residual epilogue's second output (LayerScale branch, CaiT) is not "
-                         "available in this mode; use compute_dtype='fp32'")
+        # CaiT's LayerScale residual x + gamma * f(x) with the branch output f kept for d gamma (models/cait.py:143-150): the
+        # tile kernel writes that second output in the OPERAND dtype (bf16 here), so the mode takes three steps, each the
+        # reference's own rounding: f = A W^T + b (three-product GEMM, fp32), out = gamma * f, out += x
+        if k.get("rowscale") is not None or not (C.is_contiguous() and k["R"].is_contiguous()):
+            raise VitmiError("compute_dtype='bf16x3': LayerScale residual with a DropPath row scale / strided rows is not built")
+        f, R_, gamma = k.pop("C2"), k.pop("R"), k.pop("gamma", None)
+        k.pop("epilogue")
+        _engine_gemm_split3(eng, A, B, f, **k)
+        ops.scale_cast(f, C, gamma, M=C.shape[0], N=C.shape[1])
+        ops.axpy(R_.reshape(-1), C.reshape(-1), 1.0)
+        return C
     if eng.profile is None:
         return ops.gemm_split3(A, B, C, **k)
     akm, bkm = k.get("a_kmajor", True), k.get("b_kmajor", True)
