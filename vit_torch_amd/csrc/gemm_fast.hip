@@ -1241,10 +1241,19 @@ static std::atomic<int> g_band_override{-1};     // diagnostic hook: -1 = automa
 extern "C" void vitmi_debug_gemm_band(int n) { g_band_override = n; }
 static std::atomic<int> g_band_min_kb{3072};     // diagnostic hook: B matrices up to this size keep the row-major order
 extern "C" void vitmi_debug_gemm_band_kb(int kb) { g_band_min_kb = kb > 0 ? kb : 3072; }
+static int band_env_kb() {      // VITMI_GEMM_BAND_KB: the same threshold from the environment (PMC passes run one process per shape)
+  static int kb = -2;
+  if (kb == -2) {
+    const char* e = getenv("VITMI_GEMM_BAND_KB");
+    kb = e ? atoi(e) : -1;
+  }
+  return kb;
+}
 static int band_for(const GemmArgs& g, int tiles_m, int tiles_n) {
   if (g_band_override >= 0) return g_band_override;
   const int64_t b_bytes = g.N * g.K * 2;
-  if (b_bytes <= ((int64_t)g_band_min_kb << 10) || tiles_n < 2 || tiles_m < 64) return 0;
+  const int64_t min_kb = band_env_kb() > 0 ? band_env_kb() : (int64_t)g_band_min_kb;
+  if (b_bytes <= (min_kb << 10) || tiles_n < 2 || tiles_m < 64) return 0;
   const int64_t panel = (int64_t)BN * g.K * 2;
   int band = (int)((2 << 20) / panel);
   if (band < 1) band = 1;
