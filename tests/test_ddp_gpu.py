@@ -384,3 +384,16 @@ def test_shared_device_flag_only_on_the_launches_right_after_a_bucket(nccl_world
     red.finish()
     assert red.launch_flags() == 0
     torch.cuda.synchronize()
+
+
+def test_network_ddp_with_a_stock_torch_optimizer_scales_the_flat_gradient(nccl_world_of_one, lib):
+    """`opt="torch_sgd"` has no grad_scale argument: the SUM -> mean division runs over the flat gradient buffer
+    (vitmi_scale_cast in place) before `optimizer.step()`.  World of one: the factor is 1, the step must equal the plain one."""
+    from vit_torch_amd.network import Network
+    train = _net_data(2)
+    plain = Network(_net_model(11, "fp32"), opt="torch_sgd", lr=0.02, device="cuda")
+    want = plain.fit(train, None, epochs=1)
+    net = Network(_net_model(11, "fp32"), opt="torch_sgd", lr=0.02, device="cuda", ddp={"size": 1, "rank": 0, "force": True})
+    got = net.fit(net.shard(train), None, epochs=1)
+    assert got[0]["train"]["loss"] == want[0]["train"]["loss"]
+    assert torch.equal(net.model.engine().pack.flat, plain.model.engine().pack.flat)

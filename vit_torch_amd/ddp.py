@@ -23,6 +23,7 @@ collectives remain for what cannot run on RCCL: CPU tensors / the gloo backend (
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -34,7 +35,6 @@ class GradReducer:
         """force: exchange even in a world of one (exercises the RCCL stream ordering on a
         single GPU; tests only).  transport: "auto" (own RCCL communicator for GPU buffers under the "nccl" backend,
         else the process group), "rccl", or "pg"."""
-        import os
         self.pack = pack
         self.group = group
         self.force = bool(force)

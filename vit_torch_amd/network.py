@@ -241,7 +241,16 @@ class Network:
             if self._ddp_pack is not None:
                 self._exchange_module_grads()
             elif not self._grad_scale_in_optimizer:
-                self.model.engine().pack.grad.mul_(1.0 / self.world)      # stock torch.optim: no grad_scale argument
+                # stock torch.optim has no grad_scale argument: SUM -> mean over the flat gradient buffer (vitmi_scale_cast
+                # in place, the whole buffer as one row with the factor as its row scale)
+                from . import ops
+                g = self.model.engine().pack.grad
+                if g.is_cuda:
+                    if getattr(self, "_inv_world", None) is None:
+                        self._inv_world = torch.full((1,), 1.0 / self.world, dtype=torch.float32, device=g.device)
+                    ops.scale_cast(g, g, None, M=1, N=g.numel(), rowscale=self._inv_world, rows_per_group=1)
+                else:
+                    g.mul_(1.0 / self.world)
         self.optimizer.step()
         return outputs, loss
 

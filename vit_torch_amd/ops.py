@@ -101,8 +101,6 @@ def gemm_split3(A, B, C_out, *, a_kmajor=True, b_kmajor=True, epilogue=EPI_STORE
     epilogues (bf16-only on the tile kernel) become a plain fp32 product + the element-wise fp32 kernel."""
     assert A.dtype == torch.float32 and B.dtype == torch.float32 and C_out.dtype == torch.float32
     assert colsum_part is None and not aux_deriv
-    if not A.is_contiguous() and A.stride(1) != 1:
-        A = A.contiguous()
     A3 = split3(A, b_pattern=False, stacked=not a_kmajor)
     B3 = split3(B, b_pattern=True, stacked=not b_kmajor)
     if epilogue == EPI_BIAS_GELU:
