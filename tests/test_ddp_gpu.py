@@ -397,3 +397,22 @@ def test_network_ddp_with_a_stock_torch_optimizer_scales_the_flat_gradient(nccl_
     got = net.fit(net.shard(train), None, epochs=1)
     assert got[0]["train"]["loss"] == want[0]["train"]["loss"]
     assert torch.equal(net.model.engine().pack.flat, plain.model.engine().pack.flat)
+
+
+def test_network_hip_graph_with_ddp_captures_the_exchange(nccl_world_of_one, lib):
+    """`Network(hip_graph=True, ddp=...)`: the training step replays from a HIP graph that contains the bucket all-reduces on
+    the own RCCL communicator (fork event / ncclAllReduce / join event as graph nodes).  Same epochs as the eager data-parallel
+    Network; the reducer is not re-entered from Python during replays."""
+    from vit_torch_amd.network import Network
+    train = _net_data(4)
+    eager = Network(_net_model(13), opt="sgd", lr=0.02, device="cuda", ddp={"size": 1, "rank": 0, "force": True})
+    want = eager.fit(eager.shard(train), None, epochs=2)
+    net = Network(_net_model(13), opt="sgd", lr=0.02, device="cuda", hip_graph=True, ddp={"size": 1, "rank": 0, "force": True})
+    got = net.fit(net.shard(train), None, epochs=2)
+    assert net._graphed is not None and net._graphed.graph is not None
+    launched_after = len(net.reducer.launched)
+    per_step = len(set(net.reducer.launched))
+    assert launched_after <= 2 * per_step + per_step, "replays went through Python's reducer"      # warm-up + capture (+ none per replay)
+    for w, g in zip(want, got):
+        assert g["train"]["loss"] == pytest.approx(w["train"]["loss"], rel=1e-5, abs=1e-6)
+    torch.testing.assert_close(net.model.engine().pack.flat, eager.model.engine().pack.flat, rtol=1e-5, atol=1e-6)
