@@ -1192,12 +1192,13 @@ def test_gemm_ragged_m_fp32_output_never_splits_k(ops):
 
 
 # ------------------------------------------------------------- "bf16x3": fp32 products as three bf16 products ---
+@pytest.mark.parametrize("Cn", [64, 36])          # 16-byte stores (cols % 8 == 0) and the 8-byte form
 @pytest.mark.parametrize("stacked", [False, True])
 @pytest.mark.parametrize("b_pattern", [False, True])
-def test_split3_images(ops, stacked, b_pattern):
+def test_split3_images(ops, stacked, b_pattern, Cn):
     """vitmi_split3: hi = bf16(x), lo = bf16(x - hi); A pattern hi|lo|hi, B pattern hi|hi|lo, side by side (k-major) or
     stacked (k-minor).  Bit-exact against the same two roundings in torch; hi + lo recovers x to 2^-16."""
-    R, Cn = 37, 64
+    R = 37
     x = gen((R, Cn), 21) * 3.0
     out = ops.split3(dev(x), b_pattern=b_pattern, stacked=stacked).float().cpu()
     hi = x.to(torch.bfloat16).float()
