@@ -416,3 +416,31 @@ def test_network_hip_graph_with_ddp_captures_the_exchange(nccl_world_of_one, lib
     for w, g in zip(want, got):
         assert g["train"]["loss"] == pytest.approx(w["train"]["loss"], rel=1e-5, abs=1e-6)
     torch.testing.assert_close(net.model.engine().pack.flat, eager.model.engine().pack.flat, rtol=1e-5, atol=1e-6)
+
+
+def test_network_linear_evaluation_with_ddp_exchanges_the_heads_gradients(nccl_world_of_one, lib):
+    """Linear evaluation under `ddp` (frozen backbone + ClassifierHead, main.py:184-201): the head's gradients leave through
+    the reducer after its backward (one bucket), the frozen backbone is broadcast, nothing else changes: same epoch as
+    without `ddp` in a world of one."""
+    from vit_torch_amd import VisionModelZoo
+    from vit_torch_amd.network import Network
+
+    def parts(seed):
+        torch.manual_seed(seed)
+        bb = _net_model(seed)
+        bb.head = torch.nn.Identity()
+        bb.apply_head = False
+        for p in bb.parameters():
+            p.requires_grad_(False)
+        return bb, VisionModelZoo.get_classifier_head(128, [32, 10])
+
+    train = _net_data(2)
+    bb0, h0 = parts(17)
+    plain = Network(h0, opt="sgd", lr=0.05, device="cuda", frozen_model_bottom=bb0)
+    want = plain.fit(train, None, epochs=1)
+    bb1, h1 = parts(17)
+    net = Network(h1, opt="sgd", lr=0.05, device="cuda", frozen_model_bottom=bb1, ddp={"size": 1, "rank": 0, "force": True})
+    got = net.fit(net.shard(train), None, epochs=1)
+    assert len(net.reducer.launched) == len(train), "one bucket per step: the head's gradients"
+    assert got[0]["train"]["loss"] == want[0]["train"]["loss"]
+    assert torch.equal(net.model.pack.flat, plain.model.pack.flat)

@@ -51,6 +51,7 @@ class ClassifierHead(nn.Sequential):
             raise VitmiError("ClassifierHead: layers must be Linear[, GELU], ..., Linear")
         self._pack = None
         self._saved = None
+        self.reducer = None          # ddp.GradReducer (Network(ddp=...)): the head's gradients leave as one bucket after its backward
 
     def engine(self):
         """(Re)build the flat parameter buffers (after .to(device) / load_state_dict)."""
@@ -98,6 +99,18 @@ class ClassifierHead(nn.Sequential):
         return cur
 
     def _backward(self, dout, need_dx):
+        try:
+            dx = self._backward_impl(dout, need_dx)
+        except BaseException:
+            if self.reducer is not None:
+                self.reducer.abort()
+            raise
+        if self.reducer is not None:         # data-parallel linear evaluation: all of the head's gradients are final here
+            self.reducer.section_ready([p for p in self._pack.params if p.requires_grad])
+            self.reducer.finish()
+        return dx
+
+    def _backward_impl(self, dout, need_dx):
         if self._saved is None:
             raise VitmiError("backward called without a saved forward (or called twice)")
         acts, pres = self._saved
